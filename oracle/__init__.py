@@ -1,0 +1,322 @@
+"""oracle -- CPU checker for the hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; the product (heterofusionrcnn_amd) never does.  It wraps
+
+  * libhforacle.so           our C restatement (oracle/hf_oracle.c), numpy in / numpy out
+  * _ref/libhfref_{qbp,sel,itp}.so   the reference's own standalone CPU programs (g++ build)
+  * _ref/libhfref_gpu.so     the reference's CUDA kernels compiled unmodified by hipcc
+                             (device pointers; only usable on a GPU box)
+
+See oracle/README.md for how each function is pinned.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+def build(quiet=True):
+    """(Re)build libhforacle.so and, when /root/reference exists, oracle/_ref/."""
+    out = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + out.stdout + out.stderr)
+    if not quiet:
+        print(out.stdout)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libhforacle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = ctypes.CDLL(path)
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---------------------------------------------------------------- sampling
+def farthest_point_sample(npoint, xyz):
+    xyz = _f(xyz)
+    b, n, _ = xyz.shape
+    out = np.zeros((b, npoint), np.int32)
+    lib().hfo_farthest_point_sample(b, n, npoint, _p(xyz), _p(out))
+    return out
+
+
+def gather_point(inp, idx):
+    inp, idx = _f(inp), _i(idx)
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    out = np.empty((b, m, 3), np.float32)
+    lib().hfo_gather_point(b, n, m, _p(inp), _p(idx), _p(out))
+    return out
+
+
+def gather_point_grad(inp_shape, idx, out_g):
+    idx, out_g = _i(idx), _f(out_g)
+    b, n, _ = inp_shape
+    m = idx.shape[1]
+    g = np.empty((b, n, 3), np.float32)
+    lib().hfo_gather_point_grad(b, n, m, _p(out_g), _p(idx), _p(g))
+    return g
+
+
+# ---------------------------------------------------------------- grouping
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = np.empty((b, m, nsample), np.int32)
+    cnt = np.empty((b, m), np.int32)
+    lib().hfo_query_ball_point(b, n, m, ctypes.c_float(radius), nsample, _p(xyz1), _p(xyz2), _p(idx), _p(cnt))
+    return idx, cnt
+
+
+def group_point(points, idx):
+    points, idx = _f(points), _i(idx)
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    out = np.empty((b, m, ns, c), np.float32)
+    lib().hfo_group_point(b, n, c, m, ns, _p(points), _p(idx), _p(out))
+    return out
+
+
+def group_point_grad(points_shape, idx, grad_out):
+    idx, grad_out = _i(idx), _f(grad_out)
+    b, n, c = points_shape
+    _, m, ns = idx.shape
+    g = np.empty((b, n, c), np.float32)
+    lib().hfo_group_point_grad(b, n, c, m, ns, _p(grad_out), _p(idx), _p(g))
+    return g
+
+
+def select_top_k(k, dist):
+    dist = _f(dist)
+    b, m, n = dist.shape
+    outi = np.empty((b, m, n), np.int32)
+    out = np.empty((b, m, n), np.float32)
+    lib().hfo_select_top_k(b, n, m, k, _p(dist), _p(outi), _p(out))
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    val = np.empty((b, m, k), np.float32)
+    idx = np.empty((b, m, k), np.int32)
+    lib().hfo_knn_point(b, n, m, k, _p(xyz1), _p(xyz2), _p(val), _p(idx))
+    return val, idx
+
+
+# ------------------------------------------------------------- interpolate
+def three_nn(xyz1, xyz2):
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.empty((b, n, 3), np.float32)
+    idx = np.empty((b, n, 3), np.int32)
+    lib().hfo_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx))
+    return dist, idx
+
+
+def three_interpolate(points, idx, weight):
+    """channel-last API of interpolate/tf_interpolate.py:26-37: points (b,m,c) -> (b,n,c)"""
+    points, idx, weight = _f(points), _i(idx), _f(weight)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    out = np.empty((b, n, c), np.float32)
+    lib().hfo_three_interpolate_cl(b, m, c, n, _p(points), _p(idx), _p(weight), _p(out))
+    return out
+
+
+def three_interpolate_grad(points_shape, idx, weight, grad_out):
+    idx, weight, grad_out = _i(idx), _f(weight), _f(grad_out)
+    b, m, c = points_shape
+    n = idx.shape[1]
+    g = np.empty((b, m, c), np.float32)
+    lib().hfo_three_interpolate_cl_grad(b, n, c, m, _p(grad_out), _p(idx), _p(weight), _p(g))
+    return g
+
+
+def three_interpolate_cf(points, idx, weight):
+    """channel-first op layout (tf_interpolate.cpp:25-37): points (b,c,m) -> (b,c,n)"""
+    points, idx, weight = _f(points), _i(idx), _f(weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = np.empty((b, c, n), np.float32)
+    lib().hfo_three_interpolate(b, c, m, n, _p(points), _p(idx), _p(weight), _p(out))
+    return out
+
+
+def three_interpolate_cf_grad(points_shape, idx, weight, grad_out):
+    idx, weight, grad_out = _i(idx), _f(weight), _f(grad_out)
+    b, c, m = points_shape
+    n = idx.shape[1]
+    g = np.empty((b, c, m), np.float32)
+    lib().hfo_three_interpolate_grad(b, c, n, m, _p(grad_out), _p(idx), _p(weight), _p(g))
+    return g
+
+
+# ----------------------------------------------------------------- bev_iou
+def compute_bev_iou(a, b):
+    a, b = _f(a), _f(b)
+    na, nb = a.shape[0], b.shape[0]
+    ov = np.empty((na, nb), np.float32)
+    iou = np.empty((na, nb), np.float32)
+    lib().hfo_compute_bev_iou(na, _p(a), nb, _p(b), _p(ov), _p(iou))
+    return ov, iou
+
+
+def nms_mask(boxes, thresh):
+    boxes = _f(boxes)
+    n = boxes.shape[0]
+    mask = np.empty((n, (n + 63) // 64), np.uint64)
+    lib().hfo_nms_mask(_p(boxes), _p(mask), n, ctypes.c_float(thresh))
+    return mask
+
+
+def nms_sweep(mask):
+    mask = np.ascontiguousarray(mask, dtype=np.uint64)
+    n = mask.shape[0]
+    keep = np.empty((n,), np.int32)
+    kept = lib().hfo_nms_sweep(_p(mask), n, _p(keep))
+    return keep, kept
+
+
+def oriented_nms(boxes, thresh, return_count=False):
+    boxes = _f(boxes)
+    n = boxes.shape[0]
+    keep = np.empty((n,), np.int32)
+    kept = lib().hfo_oriented_nms(_p(boxes), n, ctypes.c_float(thresh), _p(keep))
+    return (keep, kept) if return_count else keep
+
+
+# ---------------------------------------------------------------- cropping
+def pc_crop_and_sample(pts, fts, intensities, mask, boxes, box_ind, resize):
+    pts, fts, intensities, boxes = _f(pts), _f(fts), _f(intensities), _f(boxes)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    box_ind = _i(box_ind)
+    bsz, npts, _ = pts.shape
+    c, ic = fts.shape[2], intensities.shape[2]
+    nb = boxes.shape[0]
+    cp = np.empty((nb, resize, 3), np.float32)
+    cf = np.empty((nb, resize, c), np.float32)
+    ci = np.empty((nb, resize, ic), np.float32)
+    cm = np.empty((nb, resize), np.uint8)
+    cn = np.empty((nb, resize), np.int32)
+    ne = np.empty((nb,), np.uint8)
+    lib().hfo_pc_crop_and_sample(_p(pts), _p(fts), _p(intensities), _p(mask), _p(boxes), _p(box_ind), nb, bsz,
+                                 npts, resize, c, ic, _p(cp), _p(cf), _p(ci), _p(cm), _p(cn), _p(ne))
+    return cp, cf, ci, cm.astype(bool), cn, ne.astype(bool)
+
+
+def pc_crop_and_sample_grad_fts(fts_shape, box_ind, crop_ind, grad_crop_fts):
+    box_ind, crop_ind, grad_crop_fts = _i(box_ind), _i(crop_ind), _f(grad_crop_fts)
+    bsz, npts, c = fts_shape
+    nb, resize = crop_ind.shape
+    g = np.empty((bsz, npts, c), np.float32)
+    lib().hfo_pc_crop_and_sample_grad_fts(_p(box_ind), _p(crop_ind), _p(grad_crop_fts), nb, bsz, npts, resize, c,
+                                          _p(g))
+    return g
+
+
+# ------------------------------------------------- reference builds (_ref/)
+def ref_available(kind):
+    """kind in {'qbp','sel','itp','gpu'}"""
+    return os.path.exists(os.path.join(_HERE, "_ref", "libhfref_%s.so" % kind))
+
+
+_ref_libs = {}
+
+
+def ref_lib(kind):
+    if kind not in _ref_libs:
+        _ref_libs[kind] = ctypes.CDLL(os.path.join(_HERE, "_ref", "libhfref_%s.so" % kind))
+    return _ref_libs[kind]
+
+
+# mangled names of the reference's standalone CPU functions (its C++ files have no extern "C"):
+#   grouping/test/query_ball_point.cpp:19,52,70   grouping/test/selection_sort.cpp   interpolate/interpolate.cpp:84,109
+_REF_QBP = "_Z20query_ball_point_cpuiiifiPKfS0_Pi"
+_REF_GROUP = "_Z15group_point_cpuiiiiiPKfPKiPf"
+_REF_GROUP_GRAD = "_Z20group_point_grad_cpuiiiiiPKfPKiPf"
+_REF_SELSORT = "_Z18selection_sort_cpuiiiiPKfPiPf"
+_REF_ITP = "_Z15interpolate_cpuiiiiPKfPKiS0_Pf"
+_REF_ITP_GRAD = "_Z20interpolate_grad_cpuiiiiPKfPKiS0_Pf"
+
+
+def ref_query_ball_point(radius, nsample, xyz1, xyz2):
+    """the reference's query_ball_point_cpu; idx pre-zeroed like its own main() does (:94)"""
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    getattr(ref_lib("qbp"), _REF_QBP)(b, n, m, ctypes.c_float(radius), nsample, _p(xyz1), _p(xyz2), _p(idx))
+    return idx
+
+
+def ref_group_point(points, idx):
+    points, idx = _f(points), _i(idx)
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    out = np.empty((b, m, ns, c), np.float32)
+    getattr(ref_lib("qbp"), _REF_GROUP)(b, n, c, m, ns, _p(points), _p(idx), _p(out))
+    return out
+
+
+def ref_group_point_grad(points_shape, idx, grad_out):
+    idx, grad_out = _i(idx), _f(grad_out)
+    b, n, c = points_shape
+    _, m, ns = idx.shape
+    g = np.zeros((b, n, c), np.float32)
+    getattr(ref_lib("qbp"), _REF_GROUP_GRAD)(b, n, c, m, ns, _p(grad_out), _p(idx), _p(g))
+    return g
+
+
+def ref_select_top_k(k, dist):
+    dist = _f(dist)
+    b, m, n = dist.shape
+    outi = np.empty((b, m, n), np.int32)
+    out = np.empty((b, m, n), np.float32)
+    getattr(ref_lib("sel"), _REF_SELSORT)(b, n, m, k, _p(dist), _p(outi), _p(out))
+    return outi, out
+
+
+def ref_three_interpolate(points, idx, weight):
+    points, idx, weight = _f(points), _i(idx), _f(weight)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    out = np.empty((b, n, c), np.float32)
+    getattr(ref_lib("itp"), _REF_ITP)(b, m, c, n, _p(points), _p(idx), _p(weight), _p(out))
+    return out
+
+
+def ref_three_interpolate_grad(points_shape, idx, weight, grad_out):
+    idx, weight, grad_out = _i(idx), _f(weight), _f(grad_out)
+    b, m, c = points_shape
+    n = idx.shape[1]
+    g = np.zeros((b, m, c), np.float32)
+    getattr(ref_lib("itp"), _REF_ITP_GRAD)(b, n, c, m, _p(grad_out), _p(idx), _p(weight), _p(g))
+    return g
