@@ -1,0 +1,93 @@
+// hf_common.h -- shared helpers for the libhfops.so HIP sources (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hfops.h"
+
+#define HF_API extern "C" __attribute__((visibility("default")))
+
+namespace hf {
+
+extern thread_local int g_last_hip_error;
+
+inline hipStream_t as_stream(hf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int hip_status(hipError_t e)
+{
+    if (e == hipSuccess) return HF_OK;
+    g_last_hip_error = static_cast<int>(e);
+    return HF_EHIP;
+}
+
+// status of the launch that was just enqueued (no synchronisation)
+inline int launch_status() { return hip_status(hipGetLastError()); }
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kNumCU = 256;      // MI355X
+constexpr int kNumXCD = 8;
+
+inline int div_up(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
+
+// ---- wave64 cross-lane primitives (DPP) ----
+// old = 0 + bound_ctrl lets hipcc fold the move into v_max_u32_dpp / v_min_u32_dpp.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, true));
+}
+
+// max / min over each 16-lane row; every lane of the row receives the result
+__device__ __forceinline__ unsigned row_max_u32(unsigned v)
+{
+    v = max(v, dpp_u32<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = max(v, dpp_u32<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = max(v, dpp_u32<0x124>(v));   // row_ror:4
+    v = max(v, dpp_u32<0x128>(v));   // row_ror:8
+    return v;
+}
+__device__ __forceinline__ unsigned row_min_u32(unsigned v)
+{
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x124>(v));
+    v = min(v, dpp_u32<0x128>(v));
+    return v;
+}
+
+// max / min over the 64 lanes of a wave, returned wave-uniform (SGPR): 4 DPP steps, then the
+// four row results are combined on the scalar unit.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    v = row_max_u32(v);
+    const unsigned a = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 0));
+    const unsigned b = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 16));
+    const unsigned c = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 32));
+    const unsigned d = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = row_min_u32(v);
+    const unsigned a = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 0));
+    const unsigned b = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 16));
+    const unsigned c = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 32));
+    const unsigned d = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
+    return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ int lane_id() { return static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int mask_prefix(unsigned long long mask)
+{
+    return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u)));
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+}  // namespace hf

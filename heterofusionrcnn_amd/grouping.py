@@ -1,0 +1,113 @@
+"""grouping ops -- same surface as the reference's grouping/tf_grouping.py:11-95."""
+import torch
+
+from . import _lib
+from ._lib import check, dev_tensor, ptr, require, stream_ptr
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    """xyz1 (B,N,3) data, xyz2 (B,M,3) queries -> idx (B,M,nsample) int32, pts_cnt (B,M) int32.
+    Reference: tf_grouping.py:11-23; non-differentiable (:26).  Rows without any hit are zeros
+    (undefined in the reference, tf_grouping.cpp:88)."""
+    radius, nsample = float(radius), int(nsample)
+    require(radius > 0, "QueryBallPoint expects positive radius")
+    require(nsample > 0, "QueryBallPoint expects positive nsample")
+    require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+    require(xyz2.dim() == 3 and xyz2.shape[2] == 3, "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+    require(xyz1.shape[0] == xyz2.shape[0], "QueryBallPoint expects xyz1 and xyz2 with the same batch_size")
+    xyz1 = dev_tensor(xyz1.detach(), torch.float32, "xyz1")
+    xyz2 = dev_tensor(xyz2.detach(), torch.float32, "xyz2")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    check(_lib.lib().hf_query_ball_point(b, n, m, radius, nsample, ptr(xyz1), ptr(xyz2), ptr(idx), ptr(cnt),
+                                         stream_ptr()), "query_ball_point")
+    return idx, cnt
+
+
+class _GroupPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
+        check(_lib.lib().hf_group_point(b, n, c, m, ns, ptr(points), ptr(idx), ptr(out), stream_ptr()), "group_point")
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, n, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, n, c = ctx.shape
+        _, m, ns = idx.shape
+        grad_out = grad_out.contiguous()
+        g = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
+        check(_lib.lib().hf_group_point_grad(b, n, c, m, ns, ptr(grad_out), ptr(idx), ptr(g), stream_ptr()),
+              "group_point_grad")
+        return g, None
+
+
+def group_point(points, idx):
+    """points (B,N,C), idx (B,M,K) int32 -> (B,M,K,C).  Reference: tf_grouping.py:44-59
+    (gradient w.r.t. points only)."""
+    require(points.dim() == 3, "GroupPoint expects (batch_size, num_points, channel) points shape")
+    require(idx.dim() == 3 and idx.shape[0] == points.shape[0],
+            "GroupPoint expects (batch_size, npoints, nsample) idx shape")
+    points = dev_tensor(points, torch.float32, "points")
+    idx = dev_tensor(idx, torch.int32, "idx")
+    return _GroupPoint.apply(points, idx)
+
+
+def query_ball_group(radius, nsample, xyz1, xyz2, center=True):
+    """Fused query_ball_point + group_point(xyz1, idx) [- xyz2]: the op pair of
+    pointnet_util.py:48-52 / 258-260 in one launch.  Returns (idx, pts_cnt, grouped_xyz);
+    grouped_xyz carries the gradient of group_point w.r.t. xyz1 (and of the centring w.r.t. xyz2)
+    only through the unfused ops -- use it where xyz needs no gradient (it never does in the
+    reference models: coordinates are inputs)."""
+    radius, nsample = float(radius), int(nsample)
+    require(radius > 0, "QueryBallPoint expects positive radius")
+    require(nsample > 0, "QueryBallPoint expects positive nsample")
+    require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+    require(xyz2.dim() == 3 and xyz2.shape[2] == 3, "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+    require(xyz1.shape[0] == xyz2.shape[0], "QueryBallPoint expects xyz1 and xyz2 with the same batch_size")
+    xyz1 = dev_tensor(xyz1.detach(), torch.float32, "xyz1")
+    xyz2 = dev_tensor(xyz2.detach(), torch.float32, "xyz2")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    grouped = torch.empty((b, m, nsample, 3), dtype=torch.float32, device=xyz1.device)
+    check(_lib.lib().hf_query_ball_group_xyz(b, n, m, radius, nsample, ptr(xyz1), ptr(xyz2), 1 if center else 0,
+                                             ptr(idx), ptr(cnt), ptr(grouped), stream_ptr()), "query_ball_group")
+    return idx, cnt, grouped
+
+
+def select_top_k(k, dist):
+    """dist (B,M,N) -> (idx (B,M,N) int32, dist_out (B,M,N)); the first k of N are the k smallest.
+    Reference: tf_grouping.py:29-38."""
+    k = int(k)
+    require(k > 0, "SelectionSort expects positive k")
+    require(dist.dim() == 3, "SelectionSort expects (b,m,n) dist shape.")
+    dist = dev_tensor(dist.detach(), torch.float32, "dist")
+    b, m, n = dist.shape
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
+    check(_lib.lib().hf_select_top_k(b, n, m, k, ptr(dist), ptr(outi), ptr(out), stream_ptr()), "select_top_k")
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    """xyz1 (B,N,C) data, xyz2 (B,M,C) queries -> (val (B,M,k) squared L2, idx (B,M,k) int32).
+    Reference: tf_grouping.py:62-95 builds |q|^2 - 2 q.p^T + |p|^2 with a batched matmul and
+    takes tf.nn.top_k of the negation; restated with the same three terms in torch (plumbing:
+    the dedicated kNN kernel is SURVEY.md 8f rank 1, not built yet)."""
+    require(xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[0] == xyz2.shape[0] and
+            xyz1.shape[2] == xyz2.shape[2], "knn_point expects (b,n,c) xyz1 and (b,m,c) xyz2")
+    r1 = (xyz1 * xyz1).sum(dim=2, keepdim=True)              # (b,n,1)
+    r2 = (xyz2 * xyz2).sum(dim=2, keepdim=True)              # (b,m,1)
+    mul = torch.matmul(xyz2, xyz1.transpose(1, 2))           # (b,m,n)
+    dist = r2 - 2 * mul + r1.transpose(1, 2)
+    val, idx = torch.topk(-dist, k=int(k), dim=2)
+    return -val, idx.to(torch.int32)

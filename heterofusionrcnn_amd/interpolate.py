@@ -1,0 +1,89 @@
+"""interpolate ops -- same surface as the reference's interpolate/tf_interpolate.py:11-49."""
+import torch
+
+from . import _lib
+from ._lib import check, dev_tensor, ptr, require, stream_ptr
+
+
+def three_nn(xyz1, xyz2):
+    """xyz1 (B,N,3) unknown, xyz2 (B,M,3) known -> dist (B,N,3) SQUARED distances, idx (B,N,3) int32.
+    Reference: tf_interpolate.py:11-23; non-differentiable."""
+    require(xyz1.dim() == 3 and xyz1.shape[2] == 3, "ThreeNN expects (b,n,3) unknown shape")
+    require(xyz2.dim() == 3 and xyz2.shape[2] == 3, "ThreeNN expects (b,m,3) known shape")
+    require(xyz1.shape[0] == xyz2.shape[0], "ThreeNN expects the same batch size")
+    require(xyz2.shape[1] > 0, "ThreeNN expects at least one known point")
+    xyz1 = dev_tensor(xyz1.detach(), torch.float32, "xyz1")
+    xyz2 = dev_tensor(xyz2.detach(), torch.float32, "xyz2")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
+    check(_lib.lib().hf_three_nn(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), stream_ptr()), "three_nn")
+    return dist, idx
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx, weight):
+        b, m, c = points.shape
+        n = idx.shape[1]
+        out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
+        check(_lib.lib().hf_three_interpolate_cl(b, m, c, n, ptr(points), ptr(idx), ptr(weight), ptr(out),
+                                                 stream_ptr()), "three_interpolate")
+        ctx.save_for_backward(idx, weight)
+        ctx.shape = (b, m, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        b, m, c = ctx.shape
+        n = idx.shape[1]
+        grad_out = grad_out.contiguous()
+        g = torch.empty((b, m, c), dtype=torch.float32, device=grad_out.device)
+        check(_lib.lib().hf_three_interpolate_cl_grad(b, n, c, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(g),
+                                                      stream_ptr()), "three_interpolate_grad")
+        return g, None, None
+
+
+def three_interpolate(points, idx, weight):
+    """points (B,M,C), idx (B,N,3) int32, weight (B,N,3) -> (B,N,C).
+    Reference: tf_interpolate.py:26-49 -- it transposes to (B,C,M), runs the channel-first op and
+    transposes back; the channel-last kernel gives the same values without the two transposes.
+    Gradient w.r.t. points only (idx, weight get None, :44-48)."""
+    require(points.dim() == 3, "ThreeInterpolate expects (b,m,c) points shape")
+    require(idx.dim() == 3 and idx.shape[2] == 3 and idx.shape[0] == points.shape[0],
+            "ThreeInterpolate expects (b,n,3) idx shape")
+    require(weight.shape == idx.shape, "ThreeInterpolate expects (b,n,3) weight shape")
+    points = dev_tensor(points, torch.float32, "points")
+    idx = dev_tensor(idx, torch.int32, "idx")
+    weight = dev_tensor(weight.detach(), torch.float32, "weight")
+    return _ThreeInterpolate.apply(points, idx, weight)
+
+
+def three_interpolate_channel_first(points, idx, weight):
+    """The raw op layout of tf_interpolate.cpp:25-37: points (B,C,M) -> (B,C,N); no autograd."""
+    require(points.dim() == 3 and idx.dim() == 3 and idx.shape[2] == 3 and weight.shape == idx.shape,
+            "ThreeInterpolate expects (b,c,m) points and (b,n,3) idx / weight")
+    points = dev_tensor(points.detach(), torch.float32, "points")
+    idx = dev_tensor(idx, torch.int32, "idx")
+    weight = dev_tensor(weight.detach(), torch.float32, "weight")
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    check(_lib.lib().hf_three_interpolate(b, c, m, n, ptr(points), ptr(idx), ptr(weight), ptr(out), stream_ptr()),
+          "three_interpolate_channel_first")
+    return out
+
+
+def three_interpolate_channel_first_grad(points_shape, idx, weight, grad_out):
+    """ThreeInterpolateGrad op (tf_interpolate.cpp:39-48): grad_out (B,C,N) -> grad_points (B,C,M)."""
+    b, c, m = points_shape
+    idx = dev_tensor(idx, torch.int32, "idx")
+    weight = dev_tensor(weight.detach(), torch.float32, "weight")
+    grad_out = dev_tensor(grad_out.detach(), torch.float32, "grad_out")
+    n = idx.shape[1]
+    g = torch.empty((b, c, m), dtype=torch.float32, device=grad_out.device)
+    check(_lib.lib().hf_three_interpolate_grad(b, c, n, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(g),
+                                               stream_ptr()), "three_interpolate_channel_first_grad")
+    return g

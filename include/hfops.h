@@ -1,0 +1,166 @@
+/*
+ * hfops.h -- C ABI of libhfops.so: the HeteroFusionRCNN point-cloud hot path as
+ * hand-written HIP kernels for MI355X (gfx950 / CDNA4).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one launcher function that the
+ * reference's TF custom-op wrappers declare `extern` in their .cpp and define in their .cu
+ * (cited per function).  Argument lists keep the reference's order and meaning; the ABI adds
+ *   - a trailing `hf_stream_t stream` (a hipStream_t; NULL = the default stream), and
+ *   - an `int` status return (HF_OK / HF_E*), never exit() (the reference exit(-1)s at
+ *     interpolate/tf_interpolate_g.cu:82-86 and bev_iou/bev_iou.cpp:14-22).
+ *
+ * Conventions (same as the reference op boundary):
+ *   - every pointer is a DEVICE pointer to a dense row-major buffer owned by the caller;
+ *   - nothing here allocates, frees, copies to the host or synchronises; all work is
+ *     enqueued on `stream`.  Ops that need scratch take it from the caller
+ *     (hf_*_workspace() says how much);
+ *   - outputs that the reference zero-/one-fills with cudaMemset inside OpKernel::Compute
+ *     (tf_grouping.cpp:204, tf_sampling.cpp:174, tf_interpolate.cpp:91-92,130,178,
+ *     bev_iou.cpp:175-176, tf_cropping.cpp:171-176) are initialised INSIDE these functions;
+ *   - shape/attribute violations that the reference rejects with OP_REQUIRES return
+ *     HF_EINVAL and launch nothing;
+ *   - stateless, re-entrant, safe to call from several host threads on different streams.
+ *
+ * Arithmetic contract: IEEE fp32, no FMA contraction, expressions evaluated in the order the
+ * reference writes them; integer outputs are bit-exact with the reference semantics
+ * (tie rules documented per function).
+ */
+#ifndef HFOPS_H
+#define HFOPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HF_OK 0
+#define HF_EINVAL (-1)     /* shape / attribute violation (OP_REQUIRES in the reference) */
+#define HF_EHIP (-2)       /* a HIP runtime call or launch failed; see hf_last_hip_error() */
+#define HF_EWORKSPACE (-3) /* caller-provided workspace missing or too small */
+
+typedef void *hf_stream_t; /* hipStream_t */
+
+/* library / error helpers */
+const char *hf_version(void);
+const char *hf_strerror(int status);
+int hf_last_hip_error(void); /* hipError_t of the last HF_EHIP on this thread */
+
+/* ------------------------------------------------------------------ sampling/ */
+
+/* replaces farthestpointsamplingLauncher(b,n,m,inp,temp,out)  sampling/tf_sampling.cpp:94
+ * (kernel sampling/tf_sampling_g.cu:105-170).  inp (b,n,3) -> out (b,m) int32; out[:,0] = 0.
+ * Tie rule among equal max-min distances: smallest (k mod 512), then smallest k.
+ * `temp` is the reference's (32,n) float scratch; this implementation keeps the running
+ * distances on chip when n <= hf_fps_onchip_limit() and then ignores it (may be NULL);
+ * above that limit it needs hf_fps_workspace(b,n) bytes there. */
+int hf_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, hf_stream_t stream);
+size_t hf_fps_workspace(int b, int n);
+int hf_fps_onchip_limit(void);
+
+/* replaces gatherpointLauncher(b,n,m,inp,idx,out)  sampling/tf_sampling.cpp:125 (kernel :172-181) */
+int hf_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out, hf_stream_t stream);
+
+/* replaces cudaMemset + scatteraddpointLauncher(b,n,m,out_g,idx,inp_g)  sampling/tf_sampling.cpp:150,174 */
+int hf_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx, float *inp_g, hf_stream_t stream);
+
+/* ------------------------------------------------------------------ grouping/ */
+
+/* replaces queryBallPointLauncher(b,n,m,radius,nsample,xyz1,xyz2,idx,pts_cnt)  grouping/tf_grouping.cpp:66
+ * (kernel grouping/tf_grouping_g.cu:3-36).  xyz1 (b,n,3) data, xyz2 (b,m,3) queries ->
+ * idx (b,m,nsample): the first nsample data indices, ascending, with
+ * max(sqrtf(|q-p|^2),1e-20f) < radius; remaining slots repeat the first hit; a query with
+ * no hit gets a row of zeros (undefined in the reference).  pts_cnt (b,m) = #hits (<= nsample),
+ * may be NULL.  radius > 0 and nsample > 0 required (tf_grouping.cpp:70-74). */
+int hf_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                        int *idx, int *pts_cnt, hf_stream_t stream);
+
+/* replaces groupPointLauncher(b,n,c,m,nsample,points,idx,out)  grouping/tf_grouping.cpp:142 (kernel :40-57) */
+int hf_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
+                   hf_stream_t stream);
+
+/* replaces cudaMemset + groupPointGradLauncher(...)  grouping/tf_grouping.cpp:173,204 (kernel :61-78) */
+int hf_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                        float *grad_points, hf_stream_t stream);
+
+/* Fused query_ball_point + group_point(xyz) in ONE launch: the pair of calls at
+ * hf/core/feature_extractors/pointnet_util.py:48-49,258-259.  Outputs are exactly those of the
+ * two separate ops; grouped_xyz (b,m,nsample,3) optionally has the query subtracted
+ * (`center` != 0: pointnet_util.py:50-52, same fp32 subtraction).  idx / pts_cnt may be NULL. */
+int hf_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                            int center, int *idx, int *pts_cnt, float *grouped_xyz, hf_stream_t stream);
+
+/* replaces selectionSortLauncher(b,n,m,k,dist,outi,out)  grouping/tf_grouping.cpp:108 (kernel :83-123) */
+int hf_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, float *out, hf_stream_t stream);
+
+/* ---------------------------------------------------------------- interpolate/ */
+
+/* replaces three_nn_gpu(b,n,m,unknown,known,dist2,idx)  interpolate/tf_interpolate.cpp:60
+ * (kernel interpolate/tf_interpolate_g.cu:22-65).  Three smallest (squared distance, index)
+ * pairs per unknown point, earlier index first on ties; unused slots (m<3) = +inf / 0. */
+int hf_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                hf_stream_t stream);
+
+/* replaces three_interpolate_gpu(b,c,m,n,points,idx,weight,out)  tf_interpolate.cpp:99 (kernel :90-110)
+ * channel-first: points (b,c,m) -> out (b,c,n) */
+int hf_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                         float *out, hf_stream_t stream);
+
+/* replaces cudaMemset + three_interpolate_grad_gpu(b,c,n,m,grad_out,idx,weight,grad_points)
+ * tf_interpolate.cpp:141,178 (kernel :133-155); channel-first */
+int hf_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                              const float *weight, float *grad_points, hf_stream_t stream);
+
+/* Channel-last forms = what the Python surface interpolate/tf_interpolate.py:26-49 exposes
+ * (it transposes (b,m,c)->(b,c,m), calls the op, transposes back).  Same values, no transposes:
+ * points (b,m,c) -> out (b,n,c);  grad_out (b,n,c) -> grad_points (b,m,c). */
+int hf_three_interpolate_cl(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
+                            float *out, hf_stream_t stream);
+int hf_three_interpolate_cl_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                 const float *weight, float *grad_points, hf_stream_t stream);
+
+/* -------------------------------------------------------------------- bev_iou/ */
+
+/* replaces cudaMemset x2 + compute_bev_iou_gpu(num_a,boxes_a,num_b,boxes_b,ans_overlap,ans_iou)
+ * bev_iou/bev_iou.cpp:144,175-177 (kernel bev_iou_g.cu:240-254).  boxes (N,5) [x1,y1,x2,y2,ry].
+ * ans_overlap / ans_iou (num_a,num_b); either may be NULL.  num_a > 0, num_b > 0 required. */
+int hf_compute_bev_iou(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans_overlap,
+                       float *ans_iou, hf_stream_t stream);
+
+/* replaces oriented_nms_gpu(boxes,mask,boxes_num,thresh)  bev_iou/bev_iou.cpp:40 (kernel bev_iou_g.cu:256-298)
+ * mask (n, ceil(n/64)) uint64, every tile written as in the reference. */
+int hf_nms_mask(const float *boxes, unsigned long long *mask, int boxes_num, float nms_overlap_thresh,
+                hf_stream_t stream);
+
+/* The whole OrientedNMSOp::Compute (bev_iou.cpp:60-116) without its cudaMalloc / blocking D2H /
+ * host sweep / H2D: mask kernel + device-resident greedy sweep.  boxes are score-sorted (N,5);
+ * keep (N) int32 = kept indices ascending, tail padded with keep[0]; *num_kept (device int,
+ * may be NULL) = count before padding.  thresh >= 0, n > 0 required. */
+size_t hf_oriented_nms_workspace(int n);
+int hf_oriented_nms(const float *boxes, int n, float thresh, int *keep, int *num_kept, void *workspace,
+                    size_t workspace_bytes, hf_stream_t stream);
+
+/* ------------------------------------------------------------------- cropping/ */
+
+/* replaces cudaMemset x6 + pccropandsample_gpu(...)  cropping/tf_cropping.cpp:100,171-180
+ * (kernel cropping/tf_cropping_g.cu:43-132).  `mask`/`crop_mask`/`non_empty_box` are 1-byte bools.
+ * Deterministic: the points of each box are taken in ascending point index (the reference's
+ * order is atomic-arrival order; ascending is the member of its output set that a
+ * single-thread launch produces).  resize > 0 required; box_ind values must lie in [0,batch). */
+int hf_pc_crop_and_sample(const float *pts, const float *fts, const float *intensities, const unsigned char *mask,
+                          const float *boxes, const int *box_ind, int num_boxes, int batch, int npts, int resize,
+                          int channel, int intensity_channel, float *crop_pts, float *crop_fts,
+                          float *crop_intensities, unsigned char *crop_mask, int *crop_ind,
+                          unsigned char *non_empty_box, hf_stream_t stream);
+
+/* replaces cudaMemset + pccropandsamplegradfts_gpu(box_ind,crop_ind,grad_crop_fts,num_boxes,npts,resize,channel,grad_fts)
+ * cropping/tf_cropping.cpp:192,225.  `batch` added so the zero fill can happen here. */
+int hf_pc_crop_and_sample_grad_fts(const int *box_ind, const int *crop_ind, const float *grad_crop_fts,
+                                   int num_boxes, int batch, int npts, int resize, int channel, float *grad_fts,
+                                   hf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HFOPS_H */

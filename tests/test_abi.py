@@ -1,0 +1,98 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every symbol include/hfops.h
+declares; the Python host layer validates arguments like the reference's OP_REQUIRES and has
+no CPU fallback.  No compute call is made here (there is no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "hfops.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from heterofusionrcnn_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(L, n), "libhfops.so does not export %s" % n
+    # and the binding table covers exactly the header
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+
+
+def test_version_and_strerror():
+    from heterofusionrcnn_amd import _lib
+    L = _lib.lib()
+    assert b"gfx950" in L.hf_version()
+    assert L.hf_strerror(0) == b"ok"
+    assert b"invalid" in L.hf_strerror(-1)
+    assert L.hf_fps_onchip_limit() == 16384
+    assert L.hf_fps_workspace(8, 16384) == 0 and L.hf_fps_workspace(2, 20000) == 2 * 20000 * 4
+    assert L.hf_oriented_nms_workspace(9000) == 9000 * 141 * 8
+
+
+def test_no_cpu_fallback():
+    import heterofusionrcnn_amd as hf
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        hf.query_ball_point(0.1, 4, torch.zeros(1, 4, 3), torch.zeros(1, 2, 3))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        hf.farthest_point_sample(2, torch.zeros(1, 4, 3))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        hf.compute_bev_iou(torch.zeros(1, 5), torch.zeros(1, 5))
+
+
+def test_argument_checks_mirror_op_requires():
+    """same conditions as the OP_REQUIRES lines (tf_grouping.cpp:70-85, tf_sampling.cpp:100-106,
+    bev_iou.cpp:52,65,156-157, tf_cropping.cpp:108-125); raised before any device work"""
+    import heterofusionrcnn_amd as hf
+    x = torch.zeros(1, 4, 3)
+    with pytest.raises(ValueError, match="positive radius"):
+        hf.query_ball_point(0.0, 4, x, x)
+    with pytest.raises(ValueError, match="positive nsample"):
+        hf.query_ball_point(0.1, 0, x, x)
+    with pytest.raises(ValueError, match="xyz1 shape"):
+        hf.query_ball_point(0.1, 4, torch.zeros(1, 4, 2), x)
+    with pytest.raises(ValueError, match="positive npoint"):
+        hf.farthest_point_sample(0, x)
+    with pytest.raises(ValueError, match="inp shape"):
+        hf.gather_point(torch.zeros(1, 4, 4), torch.zeros(1, 2, dtype=torch.int32))
+    with pytest.raises(ValueError, match="idx shape"):
+        hf.group_point(torch.zeros(2, 4, 3), torch.zeros(1, 2, 2, dtype=torch.int32))
+    with pytest.raises(ValueError, match="proposals shape"):
+        hf.compute_bev_iou(torch.zeros(0, 5), torch.zeros(1, 5))
+    with pytest.raises(ValueError, match="nms_threshold"):
+        hf.oriented_nms(torch.zeros(3, 5), -0.1)
+    with pytest.raises(ValueError, match="positive resize"):
+        hf.pc_crop_and_sample(x, x, torch.zeros(1, 4, 1), torch.zeros(1, 4, dtype=torch.bool), torch.zeros(1, 3, 8),
+                              torch.zeros(1, dtype=torch.int32), 0)
+    with pytest.raises(NotImplementedError):
+        hf.prob_sample(None, None)
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    """HF_EINVAL paths return before any HIP call, so they are testable on the CPU box"""
+    from heterofusionrcnn_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(16)
+    assert L.hf_query_ball_point(1, 4, 2, -1.0, 4, one, one, one, one, None) == _lib.HF_EINVAL
+    assert L.hf_query_ball_point(1, 4, 2, 0.1, 0, one, one, one, one, None) == _lib.HF_EINVAL
+    assert L.hf_query_ball_point(1, 4, 2, float("nan"), 4, one, one, one, one, None) == _lib.HF_EINVAL
+    assert L.hf_farthest_point_sample(1, 4, 0, one, None, one, None) == _lib.HF_EINVAL
+    assert L.hf_farthest_point_sample(1, 20000, 8, one, None, one, None) == _lib.HF_EWORKSPACE
+    assert L.hf_compute_bev_iou(0, one, 1, one, one, one, None) == _lib.HF_EINVAL
+    assert L.hf_oriented_nms(one, 8, -1.0, one, None, one, 1 << 20, None) == _lib.HF_EINVAL
+    assert L.hf_oriented_nms(one, 8, 0.5, one, None, None, 0, None) == _lib.HF_EWORKSPACE
+    assert L.hf_pc_crop_and_sample(one, one, one, one, one, one, 1, 1, 4, 0, 1, 1, one, one, one, one, one, one,
+                                   None) == _lib.HF_EINVAL
+    # empty problems are OK and launch nothing
+    assert L.hf_query_ball_point(0, 4, 2, 0.1, 4, one, one, one, one, None) == _lib.HF_OK
+    assert L.hf_group_point(0, 4, 3, 2, 2, one, one, one, None) == _lib.HF_OK

@@ -1,0 +1,531 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (1) the committed golden vectors,
+  (2) the CPU oracle on seeded inputs up to BASELINE.json's full sizes,
+  (3) the reference's own CUDA kernels compiled unmodified by hipcc (oracle/_ref/libhfref_gpu.so,
+      when the snapshot carries it),
+  (4) size-independent properties.
+Bar: integer outputs bit-exact; fp32 copies bit-exact; IoU / interpolation / gradients within 1e-5."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 fp32 for interpolated features and IoU scores"
+
+
+@pytest.fixture(scope="module")
+def hf():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import heterofusionrcnn_amd as m
+    return m
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def kitti_uniform(rng, b, n):
+    lo = np.array([-40.0, -5.0, 0.0], np.float32)
+    hi = np.array([40.0, 3.0, 70.0], np.float32)
+    return (lo + (hi - lo) * rng.random((b, n, 3), dtype=np.float32)).astype(np.float32)
+
+
+# ------------------------------------------------------------------ golden vectors
+def test_golden_grouping(hf):
+    g = load_golden("grouping_P")
+    xyz, q = dev(g["xyz"]), dev(g["new_xyz"])
+    for tag, r, ns in (("r010", 0.1, 32), ("r030", 0.3, 32), ("r005k8", 0.05, 8)):
+        idx, cnt = hf.query_ball_point(r, ns, xyz, q)
+        assert np.array_equal(host(idx), g["idx_" + tag]), tag
+        assert np.array_equal(host(cnt), g["cnt_" + tag]), tag
+    idx, cnt = hf.query_ball_point(0.02, 16, xyz, dev(g["q_rand"]))
+    assert np.array_equal(host(idx), g["idx_rand"]) and np.array_equal(host(cnt), g["cnt_rand"])
+    idx = dev(g["idx_r010"])
+    assert np.array_equal(host(hf.group_point(xyz, idx)), g["grouped_xyz_r010"])
+    idx_f = idx[:, :64].contiguous()
+    feats = dev(g["feats"]).requires_grad_(True)
+    out = hf.group_point(feats, idx_f)
+    assert np.array_equal(host(out), g["grouped_feat_r010"])
+    out.backward(dev(g["grad_out"]))
+    np.testing.assert_allclose(host(feats.grad), g["grad_points"], rtol=0, atol=TOL)
+    # fused launch == the two ops
+    i2, c2, gx = hf.query_ball_group(0.1, 32, xyz, q, center=False)
+    assert np.array_equal(host(i2), g["idx_r010"]) and np.array_equal(host(c2), g["cnt_r010"])
+    assert np.array_equal(host(gx), g["grouped_xyz_r010"])
+    _, _, gc = hf.query_ball_group(0.1, 32, xyz, q, center=True)
+    assert np.array_equal(host(gc), g["grouped_xyz_r010"] - g["new_xyz"][:, :, None, :])
+    r = load_golden("grouping_reftest")
+    idx, cnt = hf.query_ball_point(0.3, 32, dev(r["xyz1"]), dev(r["xyz2"]))
+    assert np.array_equal(host(idx), r["idx"]) and np.array_equal(host(cnt), r["cnt"])
+    assert np.array_equal(host(hf.group_point(dev(r["points"]), idx)), r["grouped"])
+
+
+def test_golden_fps_gather(hf):
+    g = load_golden("fps")
+    for name, m in (("unit", 256), ("dup", 256), ("big", 1700), ("big2", 1400), ("tiny", 5)):
+        out = hf.farthest_point_sample(m, dev(g[name]))
+        assert out.dtype == torch.int32
+        assert np.array_equal(host(out), g[name + "_fps"]), name
+    g = load_golden("gather")
+    xyz = dev(g["xyz"]).requires_grad_(True)
+    out = hf.gather_point(xyz, dev(g["idx"]))
+    assert np.array_equal(host(out), g["out"])
+    out.backward(dev(g["out_g"]))
+    np.testing.assert_allclose(host(xyz.grad), g["inp_g"], rtol=0, atol=TOL)
+
+
+def test_golden_interpolate(hf):
+    g = load_golden("interpolate")
+    dist, idx = hf.three_nn(dev(g["unknown"]), dev(g["known"]))
+    assert np.array_equal(host(idx), g["idx"])
+    assert np.array_equal(host(dist), g["dist"])  # same fp32 expression, no contraction: bit-exact
+    d2, i2 = hf.three_nn(dev(g["unknown"][:, :16]), dev(g["known"][:, :2]))
+    assert np.array_equal(host(i2), g["idx_m2"]) and np.array_equal(host(d2), g["dist_m2"])
+    pts = dev(g["points"]).requires_grad_(True)
+    out = hf.three_interpolate(pts, idx, dev(g["weight"]))
+    np.testing.assert_allclose(host(out), g["out"], rtol=0, atol=TOL)
+    assert np.array_equal(host(out), g["out"])
+    out.backward(dev(g["grad_out"]))
+    np.testing.assert_allclose(host(pts.grad), g["grad_points"], rtol=0, atol=TOL)
+    from heterofusionrcnn_amd.interpolate import (three_interpolate_channel_first,
+                                                  three_interpolate_channel_first_grad)
+    cf = three_interpolate_channel_first(dev(g["points"].transpose(0, 2, 1)), idx, dev(g["weight"]))
+    assert np.array_equal(host(cf).transpose(0, 2, 1), g["out"])
+    gcf = three_interpolate_channel_first_grad((2, 12, 128), idx, dev(g["weight"]),
+                                               dev(g["grad_out"].transpose(0, 2, 1)))
+    np.testing.assert_allclose(host(gcf).transpose(0, 2, 1), g["grad_points"], rtol=0, atol=TOL)
+
+
+def test_golden_select_top_k(hf):
+    g = load_golden("select_top_k")
+    oi, od = hf.select_top_k(5, dev(g["dist"]))
+    assert np.array_equal(host(oi), g["outi"]) and np.array_equal(host(od), g["out"])
+
+
+def test_golden_bev_iou_nms(hf):
+    g = load_golden("bev_iou")
+    ov, iou = hf.compute_bev_iou(dev(g["demo_prop"]), dev(g["demo_gt"]))
+    assert np.array_equal(host(ov), g["demo_overlap"]) and np.array_equal(host(iou), g["demo_iou"])
+    assert host(hf.oriented_nms(dev(g["demo_nms"]), 0.5)).tolist() == [0, 1, 0]
+    ov, iou = hf.compute_bev_iou(dev(g["a"]), dev(g["b"]))
+    np.testing.assert_allclose(host(ov), g["overlap_ab"], rtol=0, atol=2e-5)   # areas up to ~8 m^2
+    np.testing.assert_allclose(host(iou), g["iou_ab"], rtol=0, atol=TOL)
+    assert ((host(iou) == 0) == (g["iou_ab"] == 0)).all()                       # the early-out is exact
+    nb = dev(g["nms_boxes"])
+    for t in (0.85, 0.8, 0.01):
+        keep, num = hf.oriented_nms(nb, t, return_count=True)
+        want = g["keep_%03d" % int(t * 100)]
+        assert np.array_equal(host(keep), want), t
+        d = np.diff(want) <= 0
+        assert int(host(num)[0]) == (1 + int(np.argmax(d)) if d.any() else len(want))
+
+
+def test_golden_crop(hf):
+    g = load_golden("crop")
+    res = hf.pc_crop_and_sample(dev(g["pts"]), dev(g["fts"]), dev(g["intensities"]), dev(g["mask"]), dev(g["boxes"]),
+                                dev(g["box_ind"]), 32)
+    for got, name in zip(res, ("crop_pts", "crop_fts", "crop_int", "crop_mask", "crop_ind", "non_empty")):
+        assert np.array_equal(host(got), g[name]), name
+    from heterofusionrcnn_amd.cropping import pc_crop_and_sample_grad_fts
+    gf = pc_crop_and_sample_grad_fts(dev(g["fts"]), dev(g["box_ind"]), res[4], dev(g["grad_crop_fts"]))
+    np.testing.assert_allclose(host(gf), g["grad_fts"], rtol=0, atol=TOL)
+    d = hf.pc_crop_and_sample(dev(g["demo_pts"]), torch.ones(1, 2, 1).cuda(),
+                              torch.arange(2, dtype=torch.float32).reshape(1, 2, 1).cuda(),
+                              torch.tensor([[True, False]]).cuda(), dev(g["demo_box"]),
+                              torch.zeros(1, dtype=torch.int32).cuda(), 1)
+    assert np.array_equal(host(d[4]), g["demo_crop_ind"]) and np.array_equal(host(d[5]), g["demo_non_empty"])
+
+
+# ------------------------------------------------------------------ oracle, seeded inputs, ragged shapes
+@pytest.mark.parametrize("b,n,m,r,ns", [(2, 1024, 256, 0.12, 32), (3, 1000, 77, 0.2, 16), (1, 5000, 300, 0.08, 64),
+                                        (2, 300, 513, 0.5, 7), (1, 64, 1, 10.0, 128)])
+def test_oracle_ball_query(hf, oracle_mod, b, n, m, r, ns):
+    rng = np.random.default_rng(b * 1000 + n)
+    x1 = rng.random((b, n, 3), dtype=np.float32)
+    x2 = rng.random((b, m, 3), dtype=np.float32)
+    idx, cnt = hf.query_ball_point(r, ns, dev(x1), dev(x2))
+    oi, oc = oracle_mod.query_ball_point(r, ns, x1, x2)
+    assert np.array_equal(host(idx), oi) and np.array_equal(host(cnt), oc)
+    i2, c2, gx = hf.query_ball_group(r, ns, dev(x1), dev(x2), center=True)
+    assert np.array_equal(host(i2), oi) and np.array_equal(host(c2), oc)
+    assert np.array_equal(host(gx), oracle_mod.group_point(x1, oi) - x2[:, :, None, :])
+
+
+def test_ball_threshold_boundary(hf, oracle_mod):
+    """points exactly at / one ulp around distance == radius: the sqrt-free test must agree with
+    max(sqrtf(s),1e-20f) < radius"""
+    rs = [0.1, 0.3, 0.5, 1.0, 2.0, 4.0, 0.37, 1e-3, 123.456]
+    for r in rs:
+        r32 = np.float32(r)
+        base = np.zeros((1, 64, 3), np.float32)
+        d = r32
+        vals = [d]
+        up, dn = d, d
+        for _ in range(20):
+            up = np.nextafter(up, np.float32(np.inf)); dn = np.nextafter(dn, np.float32(0))
+            vals += [up, dn]
+        base[0, :len(vals), 0] = np.array(vals, np.float32)
+        base[0, len(vals):, 0] = 1e6
+        q = np.zeros((1, 1, 3), np.float32)
+        idx, cnt = hf.query_ball_point(float(r32), 64, dev(base), dev(q))
+        oi, oc = oracle_mod.query_ball_point(float(r32), 64, base, q)
+        assert np.array_equal(host(idx), oi) and np.array_equal(host(cnt), oc), r
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 1024, 300), (1, 1500, 1500), (3, 700, 64), (1, 4096, 700), (2, 3000, 500),
+                                   (1, 16384, 600), (1, 20000, 128), (2, 5, 5), (1, 1, 1)])
+def test_oracle_fps(hf, oracle_mod, b, n, m):
+    rng = np.random.default_rng(n + m)
+    xyz = kitti_uniform(rng, b, n)
+    if n >= 1000:  # duplicated tail as in kitti_dataset.py:358-364 -> exact distance ties
+        xyz[:, n - n // 10:] = xyz[:, :n // 10]
+    out = hf.farthest_point_sample(m, dev(xyz))
+    assert np.array_equal(host(out), oracle_mod.farthest_point_sample(m, xyz))
+
+
+def test_oracle_fps_degenerate(hf, oracle_mod):
+    """all points identical / more samples than distinct points: every distance ties at 0"""
+    xyz = np.ones((2, 2000, 3), np.float32)
+    xyz[1, :7] = np.arange(21, dtype=np.float32).reshape(7, 3)
+    out = hf.farthest_point_sample(40, dev(xyz))
+    assert np.array_equal(host(out), oracle_mod.farthest_point_sample(40, xyz))
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 2048, 512), (1, 1000, 3), (3, 333, 1), (1, 100, 5000)])
+def test_oracle_three_nn(hf, oracle_mod, b, n, m):
+    rng = np.random.default_rng(n * 7 + m)
+    u = kitti_uniform(rng, b, n)
+    k = kitti_uniform(rng, b, m)
+    if m >= 8:
+        k[:, m // 2:m // 2 + 4] = k[:, :4]  # exact duplicates among the known points: earlier index first
+        u[:, :4] = k[:, :4]
+    dist, idx = hf.three_nn(dev(u), dev(k))
+    od, oi = oracle_mod.three_nn(u, k)
+    assert np.array_equal(host(idx), oi)
+    assert np.array_equal(host(dist), od)
+
+
+@pytest.mark.parametrize("c", [1, 3, 16, 30, 256])
+def test_oracle_interpolate_group_channels(hf, oracle_mod, c):
+    rng = np.random.default_rng(c)
+    b, n, m, ns = 2, 400, 90, 8
+    pts = rng.standard_normal((b, m, c)).astype(np.float32)
+    idx3 = rng.integers(0, m, (b, n, 3)).astype(np.int32)
+    w = rng.random((b, n, 3), dtype=np.float32)
+    p = dev(pts).requires_grad_(True)
+    out = hf.three_interpolate(p, dev(idx3), dev(w))
+    assert np.array_equal(host(out), oracle_mod.three_interpolate(pts, idx3, w))
+    go = rng.standard_normal((b, n, c)).astype(np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(host(p.grad), oracle_mod.three_interpolate_grad(pts.shape, idx3, w, go), rtol=0,
+                               atol=5e-5)
+    idx = rng.integers(0, m, (b, n, ns)).astype(np.int32)
+    p2 = dev(pts).requires_grad_(True)
+    g = hf.group_point(p2, dev(idx))
+    assert np.array_equal(host(g), oracle_mod.group_point(pts, idx))
+    go = rng.standard_normal((b, n, ns, c)).astype(np.float32)
+    g.backward(dev(go))
+    np.testing.assert_allclose(host(p2.grad), oracle_mod.group_point_grad(pts.shape, idx, go), rtol=0, atol=2e-4)
+
+
+def test_group_point_gradient_check_reference_criterion(hf):
+    """grouping/tf_grouping_op_test.py:12-28: numeric-vs-analytic gradient error < 1e-4 for group_point
+    w.r.t. points through query_ball_point indices, shapes (1,128,16)/(1,128,3)/(1,8,3), r=0.3, ns=32"""
+    r = load_golden("grouping_reftest")
+    pts = dev(r["points"]).double().float()
+    idx, _ = hf.query_ball_point(0.3, 32, dev(r["xyz1"]), dev(r["xyz2"]))
+    p = pts.clone().requires_grad_(True)
+    out = hf.group_point(p, idx)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(4):
+        gvec = torch.randn(out.shape, device="cuda", generator=gen)
+        v = torch.randn(pts.shape, device="cuda", generator=gen)
+        (analytic,) = torch.autograd.grad(out, p, gvec, retain_graph=True)
+        eps = 0.5
+        numeric = (hf.group_point(pts + eps * v, idx) - hf.group_point(pts - eps * v, idx)) / (2 * eps)
+        lhs = (analytic * v).sum().item()
+        rhs = (gvec * numeric).sum().item()
+        assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+def _rand_bev(rng, n):
+    cx, cz = rng.uniform(-40, 40, n), rng.uniform(0, 70, n)
+    l, w = np.clip(rng.normal(3.9, 0.4, n), 0.5, None), np.clip(rng.normal(1.6, 0.1, n), 0.5, None)
+    ry = rng.uniform(-np.pi, np.pi, n)
+    return np.stack([cx - l / 2, cz - w / 2, cx + l / 2, cz + w / 2, ry], 1).astype(np.float32)
+
+
+def test_oracle_bev_iou(hf, oracle_mod):
+    rng = np.random.default_rng(3)
+    a = _rand_bev(rng, 3000)
+    b = _rand_bev(rng, 64)
+    a[:500, :4] = np.repeat(b[:50, :4], 10, 0) + rng.normal(0, 0.3, (500, 4)).astype(np.float32)  # overlapping ones
+    a[500:600] = np.repeat(b[:10], 10, 0)                                                        # identical
+    a[600:610, 4] = 0.0; a[610:620, 4] = np.float32(np.pi / 2)                                    # axis aligned
+    ov, iou = hf.compute_bev_iou(dev(a), dev(b))
+    oo, oi = oracle_mod.compute_bev_iou(a, b)
+    np.testing.assert_allclose(host(iou), oi, rtol=0, atol=TOL)
+    np.testing.assert_allclose(host(ov), oo, rtol=0, atol=3e-5)
+    assert ((host(iou) == 0) == (oi == 0)).all()
+    assert (oi > 0.3).sum() > 100  # the case is not trivially all-zero
+    # odd shapes: single row / single column / non multiple of the chunk
+    for na, nb in ((1, 1), (1, 77), (130, 1), (257, 9)):
+        o2, i2 = hf.compute_bev_iou(dev(a[:na]), dev(a[500:500 + nb]))
+        e2 = oracle_mod.compute_bev_iou(a[:na], a[500:500 + nb])
+        np.testing.assert_allclose(host(i2), e2[1], rtol=0, atol=TOL)
+
+
+def _clustered(rng, clusters, copies):
+    base = _rand_bev(rng, clusters)
+    boxes = np.repeat(base, copies, 0)
+    shift = rng.normal(0, 0.3, (len(boxes), 2)).astype(np.float32)
+    boxes[:, [0, 2]] += shift[:, :1]
+    boxes[:, [1, 3]] += shift[:, 1:]
+    boxes[:, 4] += rng.normal(0, 0.1, len(boxes)).astype(np.float32)
+    return boxes[rng.permutation(len(boxes))].astype(np.float32)
+
+
+@pytest.mark.parametrize("n,thresh", [(1, 0.5), (64, 0.7), (65, 0.0), (1000, 0.8), (1500, 0.01)])
+def test_oracle_nms(hf, oracle_mod, n, thresh):
+    rng = np.random.default_rng(n)
+    boxes = _clustered(rng, max(1, n // 10), 10)[:n]
+    keep, num = hf.oriented_nms(dev(boxes), thresh, return_count=True)
+    ok, okept = oracle_mod.oriented_nms(boxes, thresh, return_count=True)
+    got = host(keep)
+    if not np.array_equal(got, ok):
+        # a flipped decision is only acceptable if some IoU sits within 1e-5 of the threshold
+        _, iou = oracle_mod.compute_bev_iou(boxes, boxes)
+        assert np.any(np.abs(iou - thresh) < TOL), "keep differs without a borderline IoU"
+        pytest.skip("borderline IoU within 1e-5 of the threshold in this random case")
+    assert int(host(num)[0]) == okept
+    # the raw mask, every tile (drop-in for oriented_nms_gpu)
+    mask = host(hf.nms_mask(dev(boxes), thresh)).view(np.uint64)
+    assert np.array_equal(mask, oracle_mod.nms_mask(boxes, thresh))
+
+
+def test_oracle_crop(hf, oracle_mod):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import box_3d_to_8co, random_boxes3d
+    rng = np.random.default_rng(9)
+    bsz, p, c, nb, r = 3, 5000, 20, 40, 100
+    pts = kitti_uniform(rng, bsz, p)
+    pts[:, :, 1] = rng.uniform(0, 2, (bsz, p)).astype(np.float32)
+    fts = rng.standard_normal((bsz, p, c)).astype(np.float32)
+    inten = rng.uniform(-.5, .5, (bsz, p, 1)).astype(np.float32)
+    mask = rng.random((bsz, p)) < 0.2
+    b3 = random_boxes3d(rng, nb)
+    b3[:, 1] = 2.2
+    b3[:, 3:6] += rng.uniform(0, 25, (nb, 1)).astype(np.float32) * np.array([1, 1, 0.2], np.float32)
+    boxes = box_3d_to_8co(b3)
+    box_ind = rng.integers(0, bsz, nb).astype(np.int32)
+    for cc, ff in ((c, fts), (3, fts[:, :, :3].copy())):  # float4 path and scalar path
+        res = hf.pc_crop_and_sample(dev(pts), dev(ff), dev(inten), dev(mask), dev(boxes), dev(box_ind), r)
+        want = oracle_mod.pc_crop_and_sample(pts, ff, inten, mask, boxes, box_ind, r)
+        for got, w, name in zip(res, want, ("pts", "fts", "int", "mask", "ind", "non_empty")):
+            assert np.array_equal(host(got), w), name
+    ne = want[5]
+    assert ne.any() and (~ne).any()
+
+
+# ------------------------------------------------------------------ full BASELINE sizes
+def test_full_size_headline_ball_group(hf, oracle_mod):
+    """B=8, N=16384, M=4096, K=32, kitti-uniform cloud, queries = gather(fps)"""
+    rng = np.random.default_rng(0)
+    xyz = kitti_uniform(rng, 8, 16384)
+    x = dev(xyz)
+    fps = hf.farthest_point_sample(4096, x)
+    assert np.array_equal(host(fps), oracle_mod.farthest_point_sample(4096, xyz))
+    new_xyz = hf.gather_point(x, fps)
+    q = host(new_xyz)
+    assert np.array_equal(q, oracle_mod.gather_point(xyz, host(fps)))
+    for r in (0.5, 2.0):
+        idx, cnt, gx = hf.query_ball_group(r, 32, x, new_xyz, center=True)
+        oi, oc = oracle_mod.query_ball_point(r, 32, xyz, q)
+        assert np.array_equal(host(idx), oi) and np.array_equal(host(cnt), oc)
+        assert np.array_equal(host(gx), oracle_mod.group_point(xyz, oi) - q[:, :, None, :])
+        i2, c2 = hf.query_ball_point(r, 32, x, new_xyz)
+        assert torch.equal(i2, idx) and torch.equal(c2, cnt)
+        assert (host(cnt) >= 1).all()  # every query is a data point
+    dist, i3 = hf.three_nn(x, new_xyz)
+    od, oi3 = oracle_mod.three_nn(xyz, q)
+    assert np.array_equal(host(i3), oi3) and np.array_equal(host(dist), od)
+
+
+def test_full_size_bev_iou_properties(hf):
+    """70 000 x 64 (BASELINE config 3): symmetry, range, self-IoU, zero pattern vs a bounding-circle bound"""
+    rng = np.random.default_rng(3)
+    a = _rand_bev(rng, 70000)
+    b = _rand_bev(rng, 64)
+    ov, iou = hf.compute_bev_iou(dev(a), dev(b))
+    ov_t, iou_t = hf.compute_bev_iou(dev(b), dev(a))
+    np.testing.assert_allclose(host(iou), host(iou_t).T, rtol=0, atol=TOL)
+    i = host(iou)
+    assert (i >= 0).all() and (i <= 1 + TOL).all() and np.isfinite(i).all()
+    ca = np.stack([(a[:, 0] + a[:, 2]) / 2, (a[:, 1] + a[:, 3]) / 2], 1)
+    cb = np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2], 1)
+    ra = np.hypot(a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]) / 2
+    rb = np.hypot(b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]) / 2
+    far = np.linalg.norm(ca[:, None] - cb[None], axis=-1) > (ra[:, None] + rb[None]) + 1e-3
+    assert (i[far] == 0).all()
+    _, self_iou = hf.compute_bev_iou(dev(b), dev(b))
+    np.testing.assert_allclose(np.diag(host(self_iou)), 1.0, atol=TOL)
+
+
+def test_full_size_nms_properties(hf):
+    """N=9000 (rpn_multiclass.config:25): kept set is an independent set, every dropped box is covered"""
+    rng = np.random.default_rng(4)
+    boxes = _clustered(rng, 300, 30)
+    bd = dev(boxes)
+    for thresh in (0.8, 0.01):
+        keep, num = hf.oriented_nms(bd, thresh, return_count=True)
+        kept = int(host(num)[0])
+        k = host(keep)
+        assert k[0] == 0 and (np.diff(k[:kept]) > 0).all() and (k[kept:] == k[0]).all()
+        kb = bd[keep[:kept].long()]
+        _, iou = hf.compute_bev_iou(kb, kb)
+        iou = host(iou)
+        np.fill_diagonal(iou, 0)
+        assert (iou <= thresh + TOL).all()                       # no kept pair above the threshold
+        dropped = np.setdiff1d(np.arange(len(boxes)), k[:kept])
+        _, cover = hf.compute_bev_iou(bd[torch.from_numpy(dropped).cuda()], kb)
+        cover = host(cover)
+        earlier = k[:kept][None, :] < dropped[:, None]
+        assert ((cover > thresh - TOL) & earlier).any(1).all()   # each dropped box has an earlier kept suppressor
+
+
+# ------------------------------------------------------------------ reference CUDA kernels compiled by hipcc
+def _ref_gpu():
+    path = os.path.join(ROOT, "oracle", "_ref", "libhfref_gpu.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libhfref_gpu.so not in this snapshot")
+    return ctypes.CDLL(path)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def test_reference_kernels_grouping_sampling(hf):
+    R = _ref_gpu()
+    rng = np.random.default_rng(21)
+    b, n, m, ns, c = 4, 4096, 1024, 32, 16
+    xyz = kitti_uniform(rng, b, n)
+    xyz[:, n - 400:] = xyz[:, :400]
+    x = dev(xyz)
+    # FPS: the real 512-thread tree reduction with its tie behaviour
+    temp = torch.empty((32, n), dtype=torch.float32, device="cuda")
+    ref_fps = torch.zeros((b, m), dtype=torch.int32, device="cuda")
+    assert R.hfref_farthest_point_sample(b, n, m, _p(x), _p(temp), _p(ref_fps)) == 0
+    fps = hf.farthest_point_sample(m, x)
+    assert torch.equal(fps, ref_fps)
+    ref_q = torch.empty((b, m, 3), dtype=torch.float32, device="cuda")
+    assert R.hfref_gather_point(b, n, m, _p(x), _p(fps), _p(ref_q)) == 0
+    q = hf.gather_point(x, fps)
+    assert torch.equal(q, ref_q)
+    for r in (0.5, 1.5, 4.0):
+        ref_idx = torch.zeros((b, m, ns), dtype=torch.int32, device="cuda")
+        ref_cnt = torch.zeros((b, m), dtype=torch.int32, device="cuda")
+        assert R.hfref_query_ball_point(b, n, m, ctypes.c_float(r), ns, _p(x), _p(q), _p(ref_idx), _p(ref_cnt)) == 0
+        idx, cnt = hf.query_ball_point(r, ns, x, q)
+        assert torch.equal(idx, ref_idx) and torch.equal(cnt, ref_cnt), r
+    feats = dev(rng.standard_normal((b, n, c)).astype(np.float32))
+    ref_g = torch.empty((b, m, ns, c), dtype=torch.float32, device="cuda")
+    assert R.hfref_group_point(b, n, c, m, ns, _p(feats), _p(idx), _p(ref_g)) == 0
+    assert torch.equal(hf.group_point(feats, idx), ref_g)
+    go = dev(rng.standard_normal((b, m, ns, c)).astype(np.float32))
+    ref_gp = torch.zeros((b, n, c), dtype=torch.float32, device="cuda")
+    assert R.hfref_group_point_grad(b, n, c, m, ns, _p(go), _p(idx), _p(ref_gp)) == 0
+    f2 = feats.clone().requires_grad_(True)
+    hf.group_point(f2, idx).backward(go)
+    torch.testing.assert_close(f2.grad, ref_gp, rtol=0, atol=2e-4)   # atomics: order differs, sums of <= ~100 terms
+
+
+def test_reference_kernels_bev_iou(hf, oracle_mod):
+    R = _ref_gpu()
+    rng = np.random.default_rng(22)
+    a = _clustered(rng, 60, 10)
+    b = a[:64].copy()
+    ad, bd = dev(a), dev(b)
+    ref_ov = torch.zeros((len(a), len(b)), device="cuda")
+    ref_iou = torch.zeros((len(a), len(b)), device="cuda")
+    assert R.hfref_compute_bev_iou(len(a), _p(ad), len(b), _p(bd), _p(ref_ov), _p(ref_iou)) == 0
+    ov, iou = hf.compute_bev_iou(ad, bd)
+    torch.testing.assert_close(iou, ref_iou, rtol=0, atol=TOL)
+    torch.testing.assert_close(ov, ref_ov, rtol=0, atol=3e-5)
+    assert torch.equal(iou == 0, ref_iou == 0)
+    # NMS: reference mask kernel + the host sweep of bev_iou.cpp:87-112 (restated in the oracle)
+    n = len(a)
+    cb = (n + 63) // 64
+    for thresh in (0.7, 0.05):
+        ref_mask = torch.zeros((n, cb), dtype=torch.int64, device="cuda")
+        assert R.hfref_nms_mask(_p(ad), _p(ref_mask), n, ctypes.c_float(thresh)) == 0
+        want, kept = oracle_mod.nms_sweep(host(ref_mask).view(np.uint64))
+        keep, num = hf.oriented_nms(ad, thresh, return_count=True)
+        if not np.array_equal(host(keep), want):
+            assert (torch.abs(ref_iou - thresh) < TOL).any(), "keep differs from the reference kernels"
+        else:
+            assert int(host(num)[0]) == kept
+            assert torch.equal(hf.nms_mask(ad, thresh), ref_mask)
+
+
+def test_reference_kernels_crop(hf):
+    """the reference appends in atomic order: compare as sets (and exactly where cnt <= R leaves no choice)"""
+    R = _ref_gpu()
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import box_3d_to_8co, random_boxes3d
+    rng = np.random.default_rng(23)
+    bsz, p, c, nb, r = 2, 4096, 8, 24, 64
+    pts = kitti_uniform(rng, bsz, p)
+    pts[:, :, 1] = rng.uniform(0, 2, (bsz, p)).astype(np.float32)
+    b3 = random_boxes3d(rng, nb)
+    b3[:, 1] = 2.2
+    b3[:, 3:6] += rng.uniform(0, 12, (nb, 1)).astype(np.float32) * np.array([1, 1, 0.3], np.float32)
+    t = dict(pts=dev(pts), fts=dev(rng.standard_normal((bsz, p, c)).astype(np.float32)),
+             inten=dev(rng.uniform(-.5, .5, (bsz, p, 1)).astype(np.float32)), mask=dev(rng.random((bsz, p)) < 0.2),
+             boxes=dev(box_3d_to_8co(b3)), box_ind=dev(rng.integers(0, bsz, nb).astype(np.int32)))
+    mine = hf.pc_crop_and_sample(t["pts"], t["fts"], t["inten"], t["mask"], t["boxes"], t["box_ind"], r)
+    ref = [torch.zeros_like(x) for x in mine]
+    ref[5].fill_(True)
+    assert R.hfref_pc_crop_and_sample(_p(t["pts"]), _p(t["fts"]), _p(t["inten"]), _p(t["mask"]), _p(t["boxes"]),
+                                      _p(t["box_ind"]), nb, bsz, p, r, c, 1, *[_p(x) for x in ref]) == 0
+    assert torch.equal(mine[5], ref[5])
+    mi, ri = host(mine[4]), host(ref[4])
+    checked = 0
+    for bx in range(nb):
+        if not host(mine[5])[bx]:
+            continue
+        row = mi[bx]
+        cnt = next((s for s in range(1, r) if row[s] <= row[s - 1]), r)
+        if cnt < r:  # all inside points taken: same set, ours ascending; pad slots are copies of taken ones
+            assert sorted(set(ri[bx].tolist())) == row[:cnt].tolist()
+            checked += 1
+    assert checked >= 3
+
+
+# ------------------------------------------------------------------ streams / re-entrancy
+def test_runs_on_the_callers_stream(hf, oracle_mod):
+    rng = np.random.default_rng(5)
+    x1 = rng.random((2, 2048, 3), dtype=np.float32)
+    x2 = rng.random((2, 256, 3), dtype=np.float32)
+    s = torch.cuda.Stream()
+    a, b = dev(x1), dev(x2)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        idx, cnt = hf.query_ball_point(0.1, 16, a, b)
+        fps = hf.farthest_point_sample(64, a)
+    s.synchronize()
+    oi, oc = oracle_mod.query_ball_point(0.1, 16, x1, x2)
+    assert np.array_equal(host(idx), oi) and np.array_equal(host(fps), oracle_mod.farthest_point_sample(64, x1))
