@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's measurement contract for the hot path.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic input: the PointNet++ SA+FP
+stack of BASELINE.json configs[1] (16384 -> 4096 -> 1024 -> 256 points, K = 32, fp32), forward +
+backward + Adam step, on B = 8 KITTI-shaped frames per GPU already resident in HBM.  With N > 1
+every rank runs the same per-GPU batch (weak scaling, the reference's own data-parallel mode:
+hf/experiments/mpi_run_training.sh + hvd.DistributedOptimizer, hf/core/trainer.py:71) and the
+gradients are all-reduced over RCCL by DistributedDataParallel.
+
+Rank 0 prints ONE JSON line: frames/s (whole job), plus
+  roofline      the fused query_ball_point+group_point kernel at the headline shape
+                (B=8, N=16384, M=4096, K=32), timed live with HIP events inside the timed steps;
+  cpu_baseline  the CPU oracle's op chain for the same stack (no GPU, 1 core), bounded sample;
+  extra         per-op device times and the bev_iou Gboxpairs/s figure BASELINE.json also names.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+B, N0, KNN = 8, 16384, 32
+SA = ((4096, 0.5, 32, (32, 32, 64)), (1024, 1.0, 32, (64, 96, 128)), (256, 2.0, 32, (128, 196, 256)))
+FP = ((256, 256), (256, 256), (128, 128))
+
+
+def kitti_uniform(rng, b, n):
+    lo = np.array([-40.0, -5.0, 0.0], np.float32)
+    hi = np.array([40.0, 3.0, 70.0], np.float32)
+    return (lo + (hi - lo) * rng.random((b, n, 3), dtype=np.float32)).astype(np.float32)
+
+
+def rand_bev(rng, n):
+    cx, cz = rng.uniform(-40, 40, n), rng.uniform(0, 70, n)
+    l, w = np.clip(rng.normal(3.9, 0.4, n), 0.5, None), np.clip(rng.normal(1.6, 0.1, n), 0.5, None)
+    ry = rng.uniform(-np.pi, np.pi, n)
+    return np.stack([cx - l / 2, cz - w / 2, cx + l / 2, cz + w / 2, ry], 1).astype(np.float32)
+
+
+def ball_group_bytes(b, n, m, k):
+    """algorithmic bytes of ONE fused launch: read xyz1, xyz2 once; write idx, pts_cnt, grouped_xyz once
+    (qbp 4*3*B*(N+M) + 4*B*M*(K+1), plus the grouped (B,M,K,3) output; the fused kernel
+    never re-reads idx or xyz, so those two terms of the two-op sum 24 641 536 B are not counted)."""
+    return 4 * 3 * b * (n + m) + 4 * b * m * (k + 1) + 4 * b * m * k * 3
+
+
+class EventTimer:
+    """HIP events on the current torch stream around selected launches inside the timed region."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def wrap(self, fn, match):
+        def inner(*args, **kwargs):
+            if self.enabled and match(*args, **kwargs):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*args, **kwargs)
+                e1.record()
+                self.pairs.append((e0, e1))
+                return out
+            return fn(*args, **kwargs)
+        return inner
+
+    def mean_us(self):
+        if not self.pairs:
+            return None
+        return 1e3 * sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)
+
+
+def time_op(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / iters  # us
+
+
+def per_op_table(hf, xyz):
+    """device time of each op at the headline shapes (us per launch)"""
+    t = {}
+    fps = hf.farthest_point_sample(4096, xyz)
+    new_xyz = hf.gather_point(xyz, fps)
+    t["fps_16384_to_4096_us"] = time_op(lambda: hf.farthest_point_sample(4096, xyz), iters=5, warm=1)
+    t["fps_us_per_round"] = t["fps_16384_to_4096_us"] / 4095.0
+    t["gather_point_us"] = time_op(lambda: hf.gather_point(xyz, fps))
+    t["query_ball_point_us"] = time_op(lambda: hf.query_ball_point(0.5, KNN, xyz, new_xyz))
+    idx, _ = hf.query_ball_point(0.5, KNN, xyz, new_xyz)
+    t["group_point_c3_us"] = time_op(lambda: hf.group_point(xyz, idx))
+    t["ball_group_fused_us"] = time_op(lambda: hf.query_ball_group(0.5, KNN, xyz, new_xyz, True))
+    f64 = torch.randn(B, N0, 64, device="cuda")
+    t["group_point_c64_us"] = time_op(lambda: hf.group_point(f64, idx))
+    t["group_point_c64_GBs"] = (4 * B * N0 * 64 + 4 * B * 4096 * KNN + 4 * B * 4096 * KNN * 64) / t["group_point_c64_us"] / 1e3
+    t["three_nn_us"] = time_op(lambda: hf.three_nn(xyz, new_xyz))
+    dist, i3 = hf.three_nn(xyz, new_xyz)
+    w = torch.rand(B, N0, 3, device="cuda")
+    p256 = torch.randn(B, 4096, 256, device="cuda")
+    t["three_interpolate_c256_us"] = time_op(lambda: hf.three_interpolate(p256, i3, w))
+    t["three_interpolate_c256_GBs"] = (4 * B * 4096 * 256 + 2 * 4 * 3 * B * N0 + 4 * B * N0 * 256) / t["three_interpolate_c256_us"] / 1e3
+    rng = np.random.default_rng(3)
+    a = torch.from_numpy(rand_bev(rng, 70000)).cuda()
+    g = torch.from_numpy(rand_bev(rng, 64)).cuda()
+    t["bev_iou_70000x64_us"] = time_op(lambda: hf.compute_bev_iou(a, g))
+    t["bev_iou_Gboxpairs_per_s"] = 70000 * 64 / t["bev_iou_70000x64_us"] / 1e3
+    nb = torch.from_numpy(rand_bev(rng, 9000)).cuda()
+    t["oriented_nms_9000_us"] = time_op(lambda: hf.oriented_nms(nb, 0.8), iters=5, warm=1)
+    return {k: round(v, 3) for k, v in t.items()}
+
+
+def cpu_baseline(frames):
+    """The CPU oracle's op chain for the same SA+FP stack (forward ops + the three backward ops),
+    one core, `frames` frames of the bench workload.  MLP GEMMs are not part of the custom-op path
+    and are not included on either side of this figure."""
+    import oracle
+    rng = np.random.default_rng(0)
+    xyz0 = kitti_uniform(rng, frames, N0)
+    t0 = time.perf_counter()
+    xyzs, idxs = [xyz0], []
+    chans = [1, 64, 128, 256]
+    for lvl, (npoint, radius, ns, _) in enumerate(SA):
+        x = xyzs[-1]
+        fps = oracle.farthest_point_sample(npoint, x)
+        nx = oracle.gather_point(x, fps)
+        idx, _ = oracle.query_ball_point(radius, ns, x, nx)
+        oracle.group_point(x, idx)
+        feats = np.zeros((frames, x.shape[1], chans[lvl]), np.float32)
+        g = oracle.group_point(feats, idx)
+        oracle.group_point_grad(feats.shape, idx, g)
+        xyzs.append(nx)
+        idxs.append(idx)
+    fpc = [256, 256, 256]
+    for lvl in range(len(SA) - 1, -1, -1):
+        dist, i3 = oracle.three_nn(xyzs[lvl], xyzs[lvl + 1])
+        pts = np.zeros((frames, xyzs[lvl + 1].shape[1], fpc[lvl]), np.float32)
+        w = np.full(dist.shape, 1.0 / 3.0, np.float32)
+        out = oracle.three_interpolate(pts, i3, w)
+        oracle.three_interpolate_grad(pts.shape, i3, w, out)
+    dt = time.perf_counter() - t0
+    res = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frame(s) of the bench workload, custom-op chain only (FPS, gather, ball query, group(+grad), "
+                     "three_nn, three_interpolate(+grad) at all 3 SA / 3 FP levels), oracle/hf_oracle.c, 1 thread, "
+                     "%.1f s" % (frames, dt)}
+    # the reference's own CPU program for the headline pair, where oracle/_ref was built
+    if oracle.ref_available("qbp"):
+        x, q = xyz0[:1], xyzs[1][:1]
+        t1 = time.perf_counter()
+        ridx = oracle.ref_query_ball_point(0.5, KNN, x, q)
+        oracle.ref_group_point(x, ridx)
+        res["reference_qbp_group_s_per_frame"] = round(time.perf_counter() - t1, 4)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-op-table", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import heterofusionrcnn_amd as hf
+    from heterofusionrcnn_amd import modules
+
+    timer = EventTimer()
+    headline = lambda radius, nsample, xyz1, xyz2, center=True: (xyz1.shape[1] == N0 and xyz2.shape[1] == SA[0][0])
+    modules.query_ball_group = timer.wrap(modules.query_ball_group, headline)
+
+    torch.manual_seed(1234)  # same initial weights on every rank (the reference broadcasts from rank 0)
+    model = modules.PointnetSAFPStack(in_channel=1, sa=SA, fp=FP).cuda()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=64,
+                                                        gradient_as_bucket_view=True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3 * world)  # lr x world size: optimizer_builder.py:105
+
+    rng = np.random.default_rng(1000 + rank)                   # rank-sharded synthetic frames
+    xyz = torch.from_numpy(kitti_uniform(rng, B, N0)).cuda()
+    intensity = torch.from_numpy(rng.uniform(-0.5, 0.5, (B, N0, 1)).astype(np.float32)).cuda()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net(xyz, intensity)
+        loss = out.mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    result = None
+    if rank == 0:
+        frames = world * B * args.steps
+        k_us = timer.mean_us()
+        algo = ball_group_bytes(B, N0, SA[0][0], KNN)
+        achieved = algo / (k_us * 1e-6) / 1e9 if k_us else None
+        result = {
+            "metric": "KITTI frames/sec, PointNet++ SA+FP stack train step (fwd+bwd+Adam)",
+            "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SA+FP stack 16384->4096->1024->256, K=32, radii 0.5/1.0/2.0, B=8 frames per GPU, "
+                                   "fwd+bwd+Adam, fp32 (BASELINE.json configs[1])",
+                       "frames_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world},
+            "roofline": {"kernel": "query_ball_point+group_point fused (hf_query_ball_group_xyz), B=8 N=16384 M=4096 K=32",
+                         "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+                         "traffic": None, "algorithmic_bytes": algo, "avg_launch_us": round(k_us, 3) if k_us else None,
+                         "launches_timed": len(timer.pairs)},
+        }
+    if rank == 0 and world == 1:
+        if not args.no_op_table:
+            result["extra"] = per_op_table(hf, xyz)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,278 @@
+"""Host-side composition of the ops: the callers on either side of the hot path.
+
+Restates, in torch on top of the HIP ops, the Python glue of the reference that defines HOW the
+ops are chained:
+
+  sample_and_group, PointnetSAModule, PointnetSAModuleMSG, PointnetFPModule
+        hf/core/feature_extractors/pointnet_util.py:24-66,104-220,223-286,289-330
+  boxes3d_to_bev, box3d_iou, oriented_nms_3d, sb_nms
+        hf/core/compute_iou.py:7-80, hf/core/models/model_util.py:101-142
+  box_3d_to_box_8co
+        hf/core/box_8c_encoder.py:101-185
+
+The MLPs between the ops are 1x1 convolutions in the reference (tf_util.conv2d: xavier weights,
+zero bias, batch norm with decay 0.9 / epsilon 1e-3, ReLU; tf_util.py:127-203,554-581); on
+channel-last tensors that is a Linear over the last dimension, which torch runs as a rocBLAS /
+hipBLASLt GEMM.  Tensors stay channel-last (B, M, K, C) end to end, the layout the HIP gather
+kernels read and write coalesced.
+"""
+import torch
+import torch.nn as nn
+
+from .grouping import group_point, knn_point, query_ball_group, query_ball_point
+from .interpolate import three_interpolate, three_nn
+from .sampling import farthest_point_sample, gather_point
+from . import bev_iou as _bev
+
+
+class SharedMLPLayer(nn.Module):
+    """tf_util.conv2d(..., [1,1], bn=True) on a channel-last tensor: Linear + bias, BN, ReLU"""
+
+    def __init__(self, cin, cout, bn=True, bn_decay=0.9, relu=True):
+        super().__init__()
+        self.fc = nn.Linear(cin, cout, bias=True)
+        nn.init.xavier_uniform_(self.fc.weight)     # tf.contrib.layers.xavier_initializer (tf_util.py:42)
+        nn.init.zeros_(self.fc.bias)                # tf.constant_initializer(0.0) (tf_util.py:188)
+        self.bn = nn.BatchNorm1d(cout, eps=1e-3, momentum=1.0 - bn_decay) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        shape = x.shape
+        y = self.fc(x.reshape(-1, shape[-1]))
+        if self.bn is not None:
+            y = self.bn(y)                          # moments over every axis but channels (tf_util.py:571)
+        if self.relu:
+            y = torch.relu(y)
+        return y.reshape(*shape[:-1], y.shape[-1])
+
+
+def _mlp(cin, widths, bn, bn_decay):
+    layers = []
+    for w in widths:
+        layers.append(SharedMLPLayer(cin, w, bn=bn, bn_decay=bn_decay))
+        cin = w
+    return nn.Sequential(*layers), cin
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
+    """pointnet_util.py:24-66.  Returns (new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+C),
+    idx (B,npoint,nsample), grouped_xyz (B,npoint,nsample,3) centred on new_xyz).
+    Concat order is [grouped_xyz, grouped_points] (:58-60)."""
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)
+        grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
+    else:
+        # query_ball_point + group_point(xyz) + centring in one launch
+        idx, _, grouped_xyz = query_ball_group(radius, nsample, xyz, new_xyz, center=True)
+    if points is not None:
+        grouped_points = group_point(points, idx)
+        new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if use_xyz else grouped_points
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    """pointnet_util.py:69-101: one group holding every point, centroid (0,0,0)"""
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=xyz.dtype, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).repeat(b, 1, 1)
+    grouped_xyz = xyz.reshape(b, 1, n, 3)
+    if points is not None:
+        new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
+        new_points = new_points.unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+class PointnetSAModule(nn.Module):
+    """pointnet_sa_module, pointnet_util.py:104-220 (NHWC path)."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, mlp2=None, group_all=False, bn=True, bn_decay=0.9,
+                 pooling="max", knn=False, use_xyz=True):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.group_all, self.pooling, self.knn, self.use_xyz = group_all, pooling, knn, use_xyz
+        cin = in_channel + (3 if (use_xyz or in_channel == 0) else 0)
+        self.mlp, cout = _mlp(cin, mlp, bn, bn_decay)
+        if pooling == "max_and_avg":
+            cout *= 2
+        self.mlp2, cout = _mlp(cout, mlp2, bn, bn_decay) if mlp2 is not None else (None, cout)
+        self.out_channel = cout
+
+    def forward(self, xyz, points):
+        if self.group_all:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, self.use_xyz)
+        else:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group(self.npoint, self.radius, self.nsample, xyz,
+                                                                     points, self.knn, self.use_xyz)
+        new_points = self.mlp(new_points)
+        if self.pooling == "max":
+            new_points = new_points.max(dim=2, keepdim=True).values
+        elif self.pooling == "avg":
+            new_points = new_points.mean(dim=2, keepdim=True)
+        elif self.pooling == "weighted_avg":
+            dists = torch.norm(grouped_xyz, dim=-1, keepdim=True)
+            w = torch.exp(-dists * 5)
+            w = w / w.sum(dim=2, keepdim=True)
+            new_points = (new_points * w).sum(dim=2, keepdim=True)
+        elif self.pooling == "max_and_avg":
+            new_points = torch.cat([new_points.mean(dim=2, keepdim=True),
+                                    new_points.max(dim=2, keepdim=True).values], dim=-1)
+        else:
+            raise ValueError("unknown pooling %r" % self.pooling)
+        if self.mlp2 is not None:
+            new_points = self.mlp2(new_points)
+        return new_xyz, new_points.squeeze(2), idx
+
+
+class PointnetSAModuleMSG(nn.Module):
+    """pointnet_sa_module_msg, pointnet_util.py:223-286.  Concat order inside a scale is
+    [grouped_points, grouped_xyz] (:264) -- the opposite of the single-scale module."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list, bn=True, bn_decay=0.9, use_xyz=True):
+        super().__init__()
+        self.npoint, self.radius_list, self.nsample_list, self.use_xyz = npoint, radius_list, nsample_list, use_xyz
+        cin = in_channel + (3 if (use_xyz or in_channel == 0) else 0)
+        mlps, cout = [], 0
+        for widths in mlp_list:
+            m, c = _mlp(cin, widths, bn, bn_decay)
+            mlps.append(m)
+            cout += c
+        self.mlps = nn.ModuleList(mlps)
+        self.out_channel = cout
+
+    def forward(self, xyz, points):
+        new_xyz = gather_point(xyz, farthest_point_sample(self.npoint, xyz))
+        outs = []
+        for radius, nsample, mlp in zip(self.radius_list, self.nsample_list, self.mlps):
+            idx, _, grouped_xyz = query_ball_group(radius, nsample, xyz, new_xyz, center=True)
+            if points is not None:
+                grouped = group_point(points, idx)
+                if self.use_xyz:
+                    grouped = torch.cat([grouped, grouped_xyz], dim=-1)
+            else:
+                grouped = grouped_xyz
+            outs.append(mlp(grouped).max(dim=2).values)
+        return new_xyz, torch.cat(outs, dim=-1)
+
+
+def three_nn_weights(dist):
+    """pointnet_util.py:304-307: dist = max(dist, 1e-10); w = (1/dist) / sum(1/dist)"""
+    d = torch.clamp(dist, min=1e-10)
+    inv = 1.0 / d
+    return inv / inv.sum(dim=2, keepdim=True)
+
+
+class PointnetFPModule(nn.Module):
+    """pointnet_fp_module, pointnet_util.py:289-330: xyz1 dense (B,N,3), xyz2 sparse (B,M,3),
+    points1 (B,N,C1) or None, points2 (B,M,C2) -> (B,N,mlp[-1]); concat [interpolated, points1] (:311-313)."""
+
+    def __init__(self, in_channel, mlp, bn=True, bn_decay=0.9):
+        super().__init__()
+        self.mlp, self.out_channel = _mlp(in_channel, mlp, bn, bn_decay)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        dist, idx = three_nn(xyz1, xyz2)
+        interpolated = three_interpolate(points2, idx, three_nn_weights(dist))
+        new_points = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
+        return self.mlp(new_points)
+
+
+class PointnetSAFPStack(nn.Module):
+    """The synthetic SA+FP stack of BASELINE.json config 2 / SURVEY.md 8d: SA levels
+    (npoint, radius, nsample, mlp) then FP levels back to the input resolution.  Layer wiring
+    follows hf/core/feature_extractors/pointnet.py (SA down, FP up with skip links)."""
+
+    def __init__(self, in_channel=1,
+                 sa=((4096, 0.5, 32, (32, 32, 64)), (1024, 1.0, 32, (64, 96, 128)), (256, 2.0, 32, (128, 196, 256))),
+                 fp=((256, 256), (256, 256), (128, 128))):
+        super().__init__()
+        self.sa = nn.ModuleList()
+        chans = [in_channel]
+        c = in_channel
+        for npoint, radius, nsample, mlp in sa:
+            m = PointnetSAModule(npoint, radius, nsample, c, list(mlp))
+            self.sa.append(m)
+            c = m.out_channel
+            chans.append(c)
+        self.fp = nn.ModuleList()
+        for level, mlp in enumerate(fp):                       # deepest first
+            skip = chans[len(sa) - 1 - level]
+            m = PointnetFPModule(c + skip, list(mlp))
+            self.fp.append(m)
+            c = m.out_channel
+        self.out_channel = c
+
+    def forward(self, xyz, points):
+        xyzs, feats = [xyz], [points]
+        for m in self.sa:
+            nx, nf, _ = m(xyzs[-1], feats[-1])
+            xyzs.append(nx)
+            feats.append(nf)
+        up = feats[-1]
+        for level, m in enumerate(self.fp):
+            i = len(self.sa) - 1 - level
+            up = m(xyzs[i], xyzs[i + 1], feats[i], up)
+        return up
+
+
+# ---------------------------------------------------------------- IoU / NMS adapters (hf/core/compute_iou.py)
+def boxes3d_to_bev(boxes3d):
+    """compute_iou.py:7-20: (N,7)[x,y,z,l,w,h,ry] -> (N,5)[x - l/2, z - w/2, x + l/2, z + w/2, ry]"""
+    cu, cv = boxes3d[:, 0], boxes3d[:, 2]
+    half_l, half_w = boxes3d[:, 3] / 2, boxes3d[:, 4] / 2
+    return torch.stack([cu - half_l, cv - half_w, cu + half_l, cv + half_w, boxes3d[:, 6]], dim=1)
+
+
+def box3d_iou(boxes_a, boxes_b):
+    """compute_iou.py:23-64: BEV overlap x height overlap (y points down: a box spans y-h .. y)."""
+    overlaps_bev, iou_2d = _bev.compute_bev_iou(boxes3d_to_bev(boxes_a), boxes3d_to_bev(boxes_b))
+    a_min, a_max = (boxes_a[:, 1] - boxes_a[:, 5]).reshape(-1, 1), boxes_a[:, 1].reshape(-1, 1)
+    b_min, b_max = (boxes_b[:, 1] - boxes_b[:, 5]).reshape(1, -1), boxes_b[:, 1].reshape(1, -1)
+    overlaps_h = torch.clamp(torch.minimum(a_max, b_max) - torch.maximum(a_min, b_min), min=0)
+    overlaps_3d = overlaps_bev * overlaps_h
+    vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).reshape(-1, 1)
+    vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).reshape(1, -1)
+    iou_3d = overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-7)
+    return iou_3d, iou_2d
+
+
+def oriented_nms_3d(boxes, scores, thresh):
+    """compute_iou.py:67-80: to BEV, sort by score (descending), oriented NMS, map back."""
+    boxes_bev = boxes3d_to_bev(boxes)
+    sorted_idxs = torch.sort(scores, descending=True, stable=True).indices
+    keep = _bev.oriented_nms(boxes_bev[sorted_idxs].contiguous(), thresh)
+    return sorted_idxs[keep.long()].to(torch.int32)
+
+
+def sb_nms(boxes, scores, nms_iou_thresh, nms_size, fixed_num_proposal_nms=True):
+    """model_util.py:101-142 (single frame): NMS, truncate to nms_size, optionally drop the
+    duplicated padding, pad with -1.  Returns (indices (nms_size,), number before padding)."""
+    ind = oriented_nms_3d(boxes, scores, nms_iou_thresh)[:nms_size]
+    if not fixed_num_proposal_nms:
+        # tf.unique keeps first occurrences in order; the padding repeats keep[0]
+        keep = torch.ones_like(ind, dtype=torch.bool)
+        keep[1:] = ind[1:] != ind[0]
+        ind = ind[keep]
+    n = ind.shape[0]
+    if nms_size > n:
+        ind = torch.cat([ind, torch.full((nms_size - n,), -1, dtype=ind.dtype, device=ind.device)])
+    return ind, n
+
+
+def box_3d_to_box_8co(boxes_3d):
+    """box_8c_encoder.py:101-185: (N,7)[x,y,z,l,w,h,ry] -> (N,3,8) corners, order P1..P8 of :21-37."""
+    x, y, z, l, w, h, ry = [boxes_3d[:, i] for i in range(7)]
+    s, c = torch.sin(ry), torch.cos(ry)
+    hl, hw = l / 2, w / 2
+    xc = torch.stack([hl, hl, -hl, -hl, hl, hl, -hl, -hl], dim=1)
+    zero = torch.zeros_like(h)
+    yc = torch.stack([zero, zero, zero, zero, -h, -h, -h, -h], dim=1)
+    zc = torch.stack([hw, -hw, -hw, hw, hw, -hw, -hw, hw], dim=1)
+    X = c[:, None] * xc + s[:, None] * zc + x[:, None]
+    Y = yc + y[:, None]
+    Z = -s[:, None] * xc + c[:, None] * zc + z[:, None]
+    return torch.stack([X, Y, Z], dim=1)

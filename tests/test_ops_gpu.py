@@ -328,6 +328,7 @@ def test_oracle_crop(hf, oracle_mod):
     b3 = random_boxes3d(rng, nb)
     b3[:, 1] = 2.2
     b3[:, 3:6] += rng.uniform(0, 25, (nb, 1)).astype(np.float32) * np.array([1, 1, 0.2], np.float32)
+    b3[:3, 3:6] = 0.01  # empty boxes
     boxes = box_3d_to_8co(b3)
     box_ind = rng.integers(0, bsz, nb).astype(np.int32)
     for cc, ff in ((c, fts), (3, fts[:, :, :3].copy())):  # float4 path and scalar path
