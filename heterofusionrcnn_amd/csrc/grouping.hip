@@ -7,6 +7,7 @@
 // monotone, so there is one float T with  hit <=> s < T ; the host computes T exactly
 // (ball_threshold) and the kernels never take a square root.
 #include <math.h>
+#include <stdlib.h>
 
 #include "hf_common.h"
 
@@ -108,6 +109,312 @@ __global__ __launch_bounds__(kQbThreads) void qbp_bruteforce_kernel(int n, int m
 }
 
 // ------------------------------------------------------------------------------------------
+// Slab ball query (main path).  One launch, grid (S slabs, B clouds), 1024 threads per workgroup.
+//
+// A brute-force scan is B*M*N pair tests (537 M at the headline shape) although a 0.5 m ball holds a
+// handful of points; the reference's early `break` almost never fires.  Here every workgroup
+//   A  histograms the cloud's QUERIES along their widest axis (1024 bins) and cuts that axis into S
+//      quantile slabs -- every workgroup of a cloud derives the same cut from the same data, so the
+//      slabs partition the queries without any inter-workgroup communication;
+//   B  streams the N data points once and keeps only those inside the bounding box of its own
+//      queries grown by the radius (a few hundred to a few thousand points) in LDS;
+//   C  counting-sorts these candidates along the second-widest axis into bins at least one radius
+//      wide, so a query's possible neighbours are ONE contiguous run of three bins;
+//   D  one thread per query tests that run with the reference's exact fp32 expression and keeps the
+//      nsample SMALLEST data indices in a sorted LDS row (= the first nsample hits of the
+//      reference's ascending scan), counting all hits;
+//   E  all threads write idx / pts_cnt / grouped_xyz rows, padded with the first hit.
+// Results are independent of S, of the axis choice and of the candidate order: the set of hits is
+// decided by the same `s < thresh` test and the order by the data index alone.
+// ------------------------------------------------------------------------------------------
+constexpr int kSlabThreads = 1024;
+constexpr int kSlabWaves = kSlabThreads / kWave;
+constexpr int kSlabBins = 1024;       // histogram bins along the slab axis == threads
+constexpr int kSlabZBins = 1024;      // bins along the second axis
+
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
+}
+__device__ __forceinline__ float ord2f(unsigned o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// exclusive prefix sum of one int per thread over the 1024-thread workgroup; `wsum` = 16 ints of LDS
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSlabWaves; ++w) {
+        const int x = wsum[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();  // wsum reusable
+    if (total) *total = tot;
+    return base + inc - v;
+}
+
+struct SlabShared {
+    unsigned qmin[3], qmax[3];   // ordered-uint bbox of ALL queries of the cloud
+    unsigned rmin[3], rmax[3];   // bbox of this round's own queries
+    int wsum[kSlabWaves];
+    int nq;                      // own queries collected this round
+    int nc;                      // candidates in the buffer
+    int rank_base;               // running rank of own queries over the chunks of pass A4
+};
+
+template <bool GROUP>
+__global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, int nslab, float radius, float thresh,
+                                                                int nsample, int qcap, int ccap,
+                                                                const float *__restrict__ xyz1,
+                                                                const float *__restrict__ xyz2, int center,
+                                                                int *__restrict__ idx, int *__restrict__ pts_cnt,
+                                                                float *__restrict__ grouped)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // carve dynamic LDS (everything in ONE array; 16-byte aligned pieces)
+    static_assert(sizeof(SlabShared) <= 128, "SlabShared must fit its 128-byte slot");
+    SlabShared &sh = *reinterpret_cast<SlabShared *>(smem_raw);
+    int *hist = reinterpret_cast<int *>(smem_raw + 128);              // kSlabBins (reused: slab id per bin)
+    int *zstart = hist + kSlabBins;                                   // kSlabZBins + 1
+    float4 *qbuf = reinterpret_cast<float4 *>(zstart + kSlabZBins + 4);  // qcap   (x,y,z,j)
+    float4 *cand = qbuf + qcap;                                       // ccap   (x,y,z,k)
+    int *perm = reinterpret_cast<int *>(cand + ccap);                 // ccap
+    int *rows = perm + ccap;                                          // qcap * rs
+    int *hits = rows + qcap * (nsample | 1);                          // qcap  total hits per query
+    const int rs = nsample | 1;
+
+    const int t = threadIdx.x;
+    const int slab = blockIdx.x, bb = blockIdx.y;
+    const float *p1 = xyz1 + static_cast<size_t>(bb) * n * 3;
+    const float *p2 = xyz2 + static_cast<size_t>(bb) * m * 3;
+
+    // ---------------- A1: bbox of all queries ----------------
+    if (t < 3) { sh.qmin[t] = 0xffffffffu; sh.qmax[t] = 0u; }
+    hist[t] = 0;
+    __syncthreads();
+    {
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int j = t; j < m; j += kSlabThreads) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = p2[j * 3 + d];
+                lo[d] = fminf(lo[d], v);
+                hi[d] = fmaxf(hi[d], v);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&sh.qmin[d], f2ord(lo[d]));
+            atomicMax(&sh.qmax[d], f2ord(hi[d]));
+        }
+    }
+    __syncthreads();
+    float qlo[3], qhi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { qlo[d] = ord2f(sh.qmin[d]); qhi[d] = ord2f(sh.qmax[d]); }
+    int ax = 0;  // slab axis = widest query extent
+    if (qhi[1] - qlo[1] > qhi[ax] - qlo[ax]) ax = 1;
+    if (qhi[2] - qlo[2] > qhi[ax] - qlo[ax]) ax = 2;
+    const float aext = qhi[ax] - qlo[ax];
+    const float ascale = aext > 0.0f ? static_cast<float>(kSlabBins) / aext : 0.0f;
+    const float alo = qlo[ax];
+    auto abin = [&](float v) -> int {
+        int bq = static_cast<int>((v - alo) * ascale);
+        return bq < 0 ? 0 : (bq > kSlabBins - 1 ? kSlabBins - 1 : bq);
+    };
+
+    // ---------------- A2/A3: histogram -> quantile slab of every bin ----------------
+    for (int j = t; j < m; j += kSlabThreads) atomicAdd(&hist[abin(p2[j * 3 + ax])], 1);
+    __syncthreads();
+    const int hcount = hist[t];
+    const int before = block_exclusive_scan(hcount, sh.wsum, nullptr);
+    int myslab = static_cast<int>((static_cast<long long>(before) * nslab) / m);
+    if (myslab > nslab - 1) myslab = nslab - 1;
+    hist[t] = myslab;  // bin -> slab (monotone in the bin index)
+    // number of queries owned by this slab
+    const int mine = myslab == slab ? hcount : 0;
+    int nq_total;
+    (void)block_exclusive_scan(mine, sh.wsum, &nq_total);  // also orders the hist[] writes before reads
+    if (nq_total == 0) return;
+
+    // pad for every box / bin growth: > radius plus fp32 rounding of the box corners
+    float amax = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) amax = fmaxf(amax, fmaxf(fabsf(qlo[d]), fabsf(qhi[d])));
+    const float rp = radius * 1.001f + 1e-6f * amax;
+
+    const int lane = t & 63, wave = t >> 6;
+    for (int round0 = 0; round0 < nq_total; round0 += qcap) {
+        // ---------------- A4: collect this round's own queries (ranks [round0, round0+qcap)) ----------------
+        if (t == 0) { sh.nq = 0; sh.nc = 0; sh.rank_base = 0; }
+        if (t < 3) { sh.rmin[t] = 0xffffffffu; sh.rmax[t] = 0u; }
+        __syncthreads();
+        for (int j0 = 0; j0 < m; j0 += kSlabThreads) {
+            const int j = j0 + t;
+            float qx = 0.f, qy = 0.f, qz = 0.f;
+            bool own = false;
+            if (j < m) {
+                qx = p2[j * 3 + 0]; qy = p2[j * 3 + 1]; qz = p2[j * 3 + 2];
+                own = hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))] == slab;
+            }
+            const unsigned long long bal = __ballot(own);
+            if (lane == 0) sh.wsum[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int rank = sh.rank_base + mask_prefix(bal);
+            int chunk_total = 0;
+#pragma unroll
+            for (int w = 0; w < kSlabWaves; ++w) {
+                const int x = sh.wsum[w];
+                if (w < wave) rank += x;
+                chunk_total += x;
+            }
+            if (own && rank >= round0 && rank < round0 + qcap) {
+                qbuf[rank - round0] = make_float4(qx, qy, qz, __int_as_float(j));
+                atomicMin(&sh.rmin[0], f2ord(qx)); atomicMax(&sh.rmax[0], f2ord(qx));
+                atomicMin(&sh.rmin[1], f2ord(qy)); atomicMax(&sh.rmax[1], f2ord(qy));
+                atomicMin(&sh.rmin[2], f2ord(qz)); atomicMax(&sh.rmax[2], f2ord(qz));
+            }
+            __syncthreads();
+            if (t == 0) sh.rank_base += chunk_total;
+            // (rank_base is read again only after the next chunk's barrier)
+        }
+        __syncthreads();
+        const int nq = min(qcap, nq_total - round0);
+        float blo[3], bhi[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { blo[d] = ord2f(sh.rmin[d]) - rp; bhi[d] = ord2f(sh.rmax[d]) + rp; }
+        // second axis: widest extent of this round's box among the other two
+        const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        const int zx = (bhi[a1] - blo[a1]) >= (bhi[a2] - blo[a2]) ? a1 : a2;
+        const float zlo = blo[zx];
+        const float zext = bhi[zx] - blo[zx];
+        float zsize = fmaxf(rp * 1.01f, zext / static_cast<float>(kSlabZBins - 2));
+        const float zscale = 1.0f / zsize;
+        auto zbin = [&](float v) -> int {
+            int bq = static_cast<int>((v - zlo) * zscale);
+            return bq < 0 ? 0 : (bq > kSlabZBins - 1 ? kSlabZBins - 1 : bq);
+        };
+        for (int q = t; q < nq; q += kSlabThreads) hits[q] = 0;
+
+        // ---------------- B..D: stream the data points, flush the candidate buffer when it fills ----------------
+        const int step = 2 * kSlabThreads;
+        for (int base = 0; base < n; base += step) {
+            {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = base + u * kSlabThreads + t;
+                    if (k < n) {
+                        const float x = p1[k * 3 + 0], y = p1[k * 3 + 1], z = p1[k * 3 + 2];
+                        if (x >= blo[0] && x <= bhi[0] && y >= blo[1] && y <= bhi[1] && z >= blo[2] && z <= bhi[2])
+                            cand[atomicAdd(&sh.nc, 1)] = make_float4(x, y, z, __int_as_float(k));
+                    }
+                }
+            }
+            __syncthreads();
+            const int nc = sh.nc;
+            __syncthreads();  // everyone has read nc before anyone pushes again
+            const bool last = base + step >= n;
+            if (!(last || nc + step > ccap)) continue;  // keep filling (uniform decision)
+            if (nc > 0) {
+                // ---- C: counting sort of the candidates by second-axis bin ----
+                zstart[t] = 0;
+                if (t == 0) zstart[kSlabZBins] = 0;
+                __syncthreads();
+                for (int c = t; c < nc; c += kSlabThreads) {
+                    const float4 v = cand[c];
+                    atomicAdd(&zstart[zbin(zx == 0 ? v.x : (zx == 1 ? v.y : v.z))], 1);
+                }
+                __syncthreads();
+                const int zc = zstart[t];
+                const int zoff = block_exclusive_scan(zc, sh.wsum, nullptr);
+                zstart[t] = zoff;                 // start of bin t
+                if (t == kSlabThreads - 1) zstart[kSlabZBins] = zoff + zc;
+                __syncthreads();
+                for (int c = t; c < nc; c += kSlabThreads) {
+                    const float4 v = cand[c];
+                    perm[atomicAdd(&zstart[zbin(zx == 0 ? v.x : (zx == 1 ? v.y : v.z))], 1)] = c;
+                }
+                __syncthreads();
+                // zstart[b] now holds the END of bin b == start of bin b+1; start of bin 0 is 0
+                // ---- D: one thread per query ----
+                for (int q = t; q < nq; q += kSlabThreads) {
+                    const float4 qq = qbuf[q];
+                    const int bq = zbin(zx == 0 ? qq.x : (zx == 1 ? qq.y : qq.z));
+                    const int i0 = bq >= 2 ? zstart[bq - 2] : 0;                       // start of bin bq-1
+                    const int i1 = zstart[bq + 1 > kSlabZBins - 1 ? kSlabZBins - 1 : bq + 1];  // end of bin bq+1
+                    int *row = rows + q * rs;
+                    int total = hits[q];
+                    int len = total < nsample ? total : nsample;
+                    for (int i = i0; i < i1; ++i) {
+                        const float4 c = cand[perm[i]];
+                        const float dx = qq.x - c.x, dy = qq.y - c.y, dz = qq.z - c.z;
+                        const float s2 = dx * dx + dy * dy + dz * dz;
+                        if (s2 < thresh) {
+                            const int k = __float_as_int(c.w);
+                            ++total;
+                            if (len < nsample || k < row[len - 1]) {
+                                int pos = len < nsample ? len++ : len - 1;
+                                while (pos > 0 && row[pos - 1] > k) { row[pos] = row[pos - 1]; --pos; }
+                                row[pos] = k;
+                            }
+                        }
+                    }
+                    hits[q] = total;
+                }
+            }
+            __syncthreads();
+            if (t == 0) sh.nc = 0;
+            __syncthreads();
+            if (last) break;
+        }
+
+        // ---------------- E: write this round's rows ----------------
+        for (int q = t; q < nq; q += kSlabThreads) {
+            if (pts_cnt) {
+                const int j = __float_as_int(qbuf[q].w);
+                pts_cnt[static_cast<size_t>(bb) * m + j] = min(hits[q], nsample);
+            }
+        }
+        const int total_e = nq * nsample;
+        if (idx) {
+            for (int e = t; e < total_e; e += kSlabThreads) {
+                const int q = e / nsample, c = e - q * nsample;
+                const int j = __float_as_int(qbuf[q].w);
+                const int h = min(hits[q], nsample);
+                idx[(static_cast<size_t>(bb) * m + j) * nsample + c] = h == 0 ? 0 : rows[q * rs + (c < h ? c : 0)];
+            }
+        }
+        if (GROUP) {
+            for (int e = t; e < total_e * 3; e += kSlabThreads) {
+                const int qc = e / 3, d = e - qc * 3;
+                const int q = qc / nsample, c = qc - q * nsample;
+                const float4 qq = qbuf[q];
+                const int j = __float_as_int(qq.w);
+                const int h = min(hits[q], nsample);
+                const int k = h == 0 ? 0 : rows[q * rs + (c < h ? c : 0)];
+                float v = p1[k * 3 + d];
+                if (center) v = v - (d == 0 ? qq.x : (d == 1 ? qq.y : qq.z));
+                grouped[((static_cast<size_t>(bb) * m + j) * nsample + c) * 3 + d] = v;
+            }
+        }
+        __syncthreads();  // qbuf / rows / hits reused by the next round
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // group_point: out[b,j,k,:] = points[b, idx[b,j,k], :]   (tf_grouping_g.cu:40-57)
 // Row copies; VEC floats per lane so that both the gathered source row segment and the
 // destination are contiguous (16-byte accesses when c % 4 == 0).
@@ -179,10 +486,16 @@ static int grid_for(long long work_items, int block)
     return static_cast<int>(g);
 }
 
-static int launch_ball_query(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
-                             int center, int *idx, int *pts_cnt, float *grouped, hipStream_t st)
+static size_t slab_lds_bytes(int nsample, int qcap, int ccap)
 {
-    const float thresh = ball_threshold(radius);
+    return 128 + sizeof(int) * (kSlabBins + kSlabZBins + 4) + sizeof(float4) * (static_cast<size_t>(qcap) + ccap) +
+           sizeof(int) * (static_cast<size_t>(ccap) + static_cast<size_t>(qcap) * (nsample | 1) + qcap);
+}
+
+static int launch_ball_query_bruteforce(int b, int n, int m, float thresh, int nsample, const float *xyz1,
+                                        const float *xyz2, int center, int *idx, int *pts_cnt, float *grouped,
+                                        hipStream_t st)
+{
     const size_t lds = sizeof(float) * kQbTile * 3 + sizeof(int) * kQbThreads * (static_cast<size_t>(nsample | 1) + 1);
     if (lds > 160 * 1024) return HF_EINVAL;  // nsample > ~148: not used by any config
     dim3 grid(div_up(m, kQbThreads), b);
@@ -198,6 +511,46 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         hipLaunchKernelGGL((qbp_bruteforce_kernel<false>), grid, dim3(kQbThreads), lds, st, n, m, thresh, nsample,
                            xyz1, xyz2, center, idx, pts_cnt, grouped);
+    }
+    return launch_status();
+}
+
+// HF_BALL_QUERY=bruteforce forces the fallback kernel (used by the tests to cover both paths)
+static bool force_bruteforce()
+{
+    const char *e = getenv("HF_BALL_QUERY");
+    return e && e[0] == 'b';
+}
+
+static int launch_ball_query(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                             int center, int *idx, int *pts_cnt, float *grouped, hipStream_t st)
+{
+    const float thresh = ball_threshold(radius);
+    // slab kernel geometry: LDS rows hold nsample ints per query
+    int qcap, ccap;
+    if (nsample <= 32) { qcap = 256; ccap = 4096; }
+    else if (nsample <= 64) { qcap = 256; ccap = 2560; }
+    else if (nsample <= 128) { qcap = 128; ccap = 2560; }
+    else { qcap = 0; ccap = 0; }
+    const bool finite_r = radius < 3.0e18f;  // padded boxes stay finite
+    if (qcap == 0 || !finite_r || force_bruteforce() || b > 65535)
+        return launch_ball_query_bruteforce(b, n, m, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
+    // one workgroup per CU across the batch, at least ~64 queries per slab
+    int nslab = kNumCU / b;
+    if (nslab > m / 64) nslab = m / 64;
+    if (nslab < 1) nslab = 1;
+    const size_t lds = slab_lds_bytes(nsample, qcap, ccap);
+    dim3 grid(nslab, b);
+    if (grouped) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL((qbp_slab_kernel<true>), grid, dim3(kSlabThreads), lds, st, n, m, nslab, radius, thresh,
+                           nsample, qcap, ccap, xyz1, xyz2, center, idx, pts_cnt, grouped);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL((qbp_slab_kernel<false>), grid, dim3(kSlabThreads), lds, st, n, m, nslab, radius, thresh,
+                           nsample, qcap, ccap, xyz1, xyz2, center, idx, pts_cnt, grouped);
     }
     return launch_status();
 }

@@ -162,6 +162,45 @@ def test_oracle_ball_query(hf, oracle_mod, b, n, m, r, ns):
     assert np.array_equal(host(gx), oracle_mod.group_point(x1, oi) - x2[:, :, None, :])
 
 
+def test_ball_query_both_kernels_and_stress_paths(hf, oracle_mod):
+    """slab kernel: several rounds per slab (clustered queries), candidate-buffer flushes (dense data),
+    hits >> nsample, every LDS geometry (nsample 32/64/128) and the brute-force fallback (nsample > 128 or
+    HF_BALL_QUERY=bruteforce) -- all must give the oracle's rows"""
+    rng = np.random.default_rng(77)
+    cases = []
+    # clustered queries: ~2900 of 3000 queries sit in a 1 cm cube -> one slab owns them all (rounds)
+    x1 = kitti_uniform(rng, 1, 6000)
+    q = kitti_uniform(rng, 1, 3000)
+    q[0, :2900] = np.array([3.0, -1.0, 20.0], np.float32) + rng.uniform(0, 0.01, (2900, 3)).astype(np.float32)
+    x1[0, :500] = np.array([3.0, -1.0, 20.0], np.float32) + rng.uniform(-0.4, 0.4, (500, 3)).astype(np.float32)
+    cases.append((x1, q, 0.5, 32))
+    # dense data: 20000 points inside a 4 m cube, radius 1.0 -> candidate buffer flushes, hundreds of hits per ball
+    x1 = rng.uniform(0, 4, (2, 20000, 3)).astype(np.float32)
+    q = rng.uniform(0, 4, (2, 500, 3)).astype(np.float32)
+    cases.append((x1, q, 1.0, 32))
+    cases.append((x1[:, :5000], q, 0.7, 64))
+    cases.append((x1[:, :3000], q[:, :100], 1.5, 128))
+    cases.append((x1[:, :3000], q[:, :100], 1.5, 140))     # brute-force geometry
+    # all queries identical on every axis (zero extent), duplicates in the data
+    x1 = kitti_uniform(rng, 1, 4096)
+    x1[0, 2000:2100] = x1[0, 0]
+    q = np.repeat(x1[:, :1], 300, axis=1)
+    cases.append((x1, q, 0.05, 16))
+    # huge radius: every point is a hit for every query
+    cases.append((kitti_uniform(rng, 2, 700), kitti_uniform(rng, 2, 130), 500.0, 32))
+    for mode in ("", "bruteforce"):
+        os.environ["HF_BALL_QUERY"] = mode
+        try:
+            for (a, b, r, ns) in cases:
+                oi, oc = oracle_mod.query_ball_point(r, ns, a, b)
+                idx, cnt, gx = hf.query_ball_group(r, ns, dev(a), dev(b), center=False)
+                assert np.array_equal(host(idx), oi), (mode, r, ns)
+                assert np.array_equal(host(cnt), oc), (mode, r, ns)
+                assert np.array_equal(host(gx), oracle_mod.group_point(a, oi)), (mode, r, ns)
+        finally:
+            os.environ.pop("HF_BALL_QUERY", None)
+
+
 def test_ball_threshold_boundary(hf, oracle_mod):
     """points exactly at / one ulp around distance == radius: the sqrt-free test must agree with
     max(sqrtf(s),1e-20f) < radius"""
