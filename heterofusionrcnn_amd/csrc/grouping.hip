@@ -170,14 +170,30 @@ struct SlabShared {
     unsigned qmin[3], qmax[3];   // ordered-uint bbox of ALL queries of the cloud
     unsigned rmin[3], rmax[3];   // bbox of this round's own queries
     int wsum[kSlabWaves];
-    int nq;                      // own queries collected this round
-    int nc;                      // candidates in the buffer
-    int rank_base;               // running rank of own queries over the chunks of pass A4
 };
+
+// per-wave DPP reduction, then ONE lane touches LDS.  (A same-address LDS atomic issued by all 64 lanes
+// is rewritten by hipcc's atomic optimizer into a 64-iteration scalar v_readlane loop: 20 us for the six
+// bbox atomics of this kernel, measured.)
+__device__ __forceinline__ void wave_bbox_merge(const float lo[3], const float hi[3], unsigned *smin, unsigned *smax)
+{
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const unsigned a = wave_min_u32(f2ord(lo[d]));
+        const unsigned b = wave_max_u32(f2ord(hi[d]));
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&smin[d], a);
+            atomicMax(&smax[d], b);
+        }
+    }
+}
+
+constexpr int kSlabPPT = 8;   // data points prefetched into registers per thread and super-step
+constexpr int kSlabG = 8;     // lanes cooperating on one query in phase D
 
 template <bool GROUP>
 __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, int nslab, float radius, float thresh,
-                                                                int nsample, int qcap, int ccap,
+                                                                int nsample, int qcap, int ccap, int stop,
                                                                 const float *__restrict__ xyz1,
                                                                 const float *__restrict__ xyz2, int center,
                                                                 int *__restrict__ idx, int *__restrict__ pts_cnt,
@@ -190,17 +206,20 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
     int *hist = reinterpret_cast<int *>(smem_raw + 128);              // kSlabBins (reused: slab id per bin)
     int *zstart = hist + kSlabBins;                                   // kSlabZBins + 1
     float4 *qbuf = reinterpret_cast<float4 *>(zstart + kSlabZBins + 4);  // qcap   (x,y,z,j)
-    float4 *cand = qbuf + qcap;                                       // ccap   (x,y,z,k)
-    int *perm = reinterpret_cast<int *>(cand + ccap);                 // ccap
-    int *rows = perm + ccap;                                          // qcap * rs
+    float4 *cand = qbuf + qcap;                                       // ccap   (x,y,z,k) in arrival order
+    float4 *sorted = cand + ccap;                                     // ccap   the same, ordered by second-axis bin
+    int *rows = reinterpret_cast<int *>(sorted + ccap);               // qcap * rs  K smallest indices, ascending
     int *hits = rows + qcap * (nsample | 1);                          // qcap  total hits per query
+    int *stage = hits + qcap;                                         // kSlabThreads: phase-D hand-off inside a wave
     const int rs = nsample | 1;
 
     const int t = threadIdx.x;
+    const int lane = t & 63;
     const int slab = blockIdx.x, bb = blockIdx.y;
     const float *p1 = xyz1 + static_cast<size_t>(bb) * n * 3;
     const float *p2 = xyz2 + static_cast<size_t>(bb) * m * 3;
 
+    if (stop == -1) return;
     // ---------------- A1: bbox of all queries ----------------
     if (t < 3) { sh.qmin[t] = 0xffffffffu; sh.qmax[t] = 0u; }
     hist[t] = 0;
@@ -215,13 +234,10 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
                 hi[d] = fmaxf(hi[d], v);
             }
         }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            atomicMin(&sh.qmin[d], f2ord(lo[d]));
-            atomicMax(&sh.qmax[d], f2ord(hi[d]));
-        }
+        wave_bbox_merge(lo, hi, sh.qmin, sh.qmax);
     }
     __syncthreads();
+    if (stop == -2) return;
     float qlo[3], qhi[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { qlo[d] = ord2f(sh.qmin[d]); qhi[d] = ord2f(sh.qmax[d]); }
@@ -239,16 +255,31 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
     // ---------------- A2/A3: histogram -> quantile slab of every bin ----------------
     for (int j = t; j < m; j += kSlabThreads) atomicAdd(&hist[abin(p2[j * 3 + ax])], 1);
     __syncthreads();
+    if (stop == -3) return;
     const int hcount = hist[t];
     const int before = block_exclusive_scan(hcount, sh.wsum, nullptr);
-    int myslab = static_cast<int>((static_cast<long long>(before) * nslab) / m);
+    // before < m and nslab <= 256, m * nslab < 2^31 is checked on the host: 32-bit division
+    int myslab = static_cast<int>((static_cast<unsigned>(before) * static_cast<unsigned>(nslab)) / static_cast<unsigned>(m));
     if (myslab > nslab - 1) myslab = nslab - 1;
+    __syncthreads();
     hist[t] = myslab;  // bin -> slab (monotone in the bin index)
-    // number of queries owned by this slab
-    const int mine = myslab == slab ? hcount : 0;
+    __syncthreads();
+
+    // ---------------- A4a: which queries are mine; rank them (any fixed order will do) ----------------
+    // own-flags of this thread's first 32 strided queries are cached in a bit mask
+    unsigned ownmask = 0;
+    int owncnt = 0;
+    {
+        int i = 0;
+        for (int j = t; j < m; j += kSlabThreads, ++i) {
+            const bool own = hist[abin(p2[j * 3 + ax])] == slab;
+            if (own) { ++owncnt; if (i < 32) ownmask |= 1u << i; }
+        }
+    }
     int nq_total;
-    (void)block_exclusive_scan(mine, sh.wsum, &nq_total);  // also orders the hist[] writes before reads
+    const int rank0 = block_exclusive_scan(owncnt, sh.wsum, &nq_total);
     if (nq_total == 0) return;
+    if (stop == 1) return;  // diagnostic phase timing only (HF_QBP_STOP), never set in production
 
     // pad for every box / bin growth: > radius plus fp32 rounding of the box corners
     float amax = 0.0f;
@@ -256,42 +287,31 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
     for (int d = 0; d < 3; ++d) amax = fmaxf(amax, fmaxf(fabsf(qlo[d]), fabsf(qhi[d])));
     const float rp = radius * 1.001f + 1e-6f * amax;
 
-    const int lane = t & 63, wave = t >> 6;
     for (int round0 = 0; round0 < nq_total; round0 += qcap) {
-        // ---------------- A4: collect this round's own queries (ranks [round0, round0+qcap)) ----------------
-        if (t == 0) { sh.nq = 0; sh.nc = 0; sh.rank_base = 0; }
+        // ---------------- A4b: collect this round's own queries (ranks [round0, round0+qcap)) ----------------
         if (t < 3) { sh.rmin[t] = 0xffffffffu; sh.rmax[t] = 0u; }
         __syncthreads();
-        for (int j0 = 0; j0 < m; j0 += kSlabThreads) {
-            const int j = j0 + t;
-            float qx = 0.f, qy = 0.f, qz = 0.f;
-            bool own = false;
-            if (j < m) {
-                qx = p2[j * 3 + 0]; qy = p2[j * 3 + 1]; qz = p2[j * 3 + 2];
-                own = hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))] == slab;
+        {
+            float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            int rank = rank0, i = 0;
+            for (int j = t; j < m && rank < round0 + qcap && rank < rank0 + owncnt; j += kSlabThreads, ++i) {
+                bool own;
+                if (i < 32) own = (ownmask >> i) & 1u;
+                else own = hist[abin(p2[j * 3 + ax])] == slab;
+                if (!own) continue;
+                if (rank >= round0) {
+                    const float qx = p2[j * 3 + 0], qy = p2[j * 3 + 1], qz = p2[j * 3 + 2];
+                    qbuf[rank - round0] = make_float4(qx, qy, qz, __int_as_float(j));
+                    lo[0] = fminf(lo[0], qx); hi[0] = fmaxf(hi[0], qx);
+                    lo[1] = fminf(lo[1], qy); hi[1] = fmaxf(hi[1], qy);
+                    lo[2] = fminf(lo[2], qz); hi[2] = fmaxf(hi[2], qz);
+                }
+                ++rank;
             }
-            const unsigned long long bal = __ballot(own);
-            if (lane == 0) sh.wsum[wave] = __builtin_popcountll(bal);
-            __syncthreads();
-            int rank = sh.rank_base + mask_prefix(bal);
-            int chunk_total = 0;
-#pragma unroll
-            for (int w = 0; w < kSlabWaves; ++w) {
-                const int x = sh.wsum[w];
-                if (w < wave) rank += x;
-                chunk_total += x;
-            }
-            if (own && rank >= round0 && rank < round0 + qcap) {
-                qbuf[rank - round0] = make_float4(qx, qy, qz, __int_as_float(j));
-                atomicMin(&sh.rmin[0], f2ord(qx)); atomicMax(&sh.rmax[0], f2ord(qx));
-                atomicMin(&sh.rmin[1], f2ord(qy)); atomicMax(&sh.rmax[1], f2ord(qy));
-                atomicMin(&sh.rmin[2], f2ord(qz)); atomicMax(&sh.rmax[2], f2ord(qz));
-            }
-            __syncthreads();
-            if (t == 0) sh.rank_base += chunk_total;
-            // (rank_base is read again only after the next chunk's barrier)
+            wave_bbox_merge(lo, hi, sh.rmin, sh.rmax);
         }
         __syncthreads();
+        if (stop == 2) return;
         const int nq = min(qcap, nq_total - round0);
         float blo[3], bhi[3];
 #pragma unroll
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
         const int zx = (bhi[a1] - blo[a1]) >= (bhi[a2] - blo[a2]) ? a1 : a2;
         const float zlo = blo[zx];
         const float zext = bhi[zx] - blo[zx];
-        float zsize = fmaxf(rp * 1.01f, zext / static_cast<float>(kSlabZBins - 2));
+        const float zsize = fmaxf(rp * 1.01f, zext / static_cast<float>(kSlabZBins - 2));
         const float zscale = 1.0f / zsize;
         auto zbin = [&](float v) -> int {
             int bq = static_cast<int>((v - zlo) * zscale);
@@ -309,77 +329,134 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
         };
         for (int q = t; q < nq; q += kSlabThreads) hits[q] = 0;
 
-        // ---------------- B..D: stream the data points, flush the candidate buffer when it fills ----------------
-        const int step = 2 * kSlabThreads;
-        for (int base = 0; base < n; base += step) {
-            {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int k = base + u * kSlabThreads + t;
-                    if (k < n) {
-                        const float x = p1[k * 3 + 0], y = p1[k * 3 + 1], z = p1[k * 3 + 2];
-                        if (x >= blo[0] && x <= bhi[0] && y >= blo[1] && y <= bhi[1] && z >= blo[2] && z <= bhi[2])
-                            cand[atomicAdd(&sh.nc, 1)] = make_float4(x, y, z, __int_as_float(k));
-                    }
-                }
+        // ---- C + D on the current candidate buffer (nc entries); called by all threads together ----
+        auto flush = [&](int nc) {
+            // C: counting sort of the candidates by second-axis bin
+            zstart[t] = 0;
+            __syncthreads();
+            for (int c = t; c < nc; c += kSlabThreads) {
+                const float4 v = cand[c];
+                atomicAdd(&zstart[zbin(zx == 0 ? v.x : (zx == 1 ? v.y : v.z))], 1);
             }
             __syncthreads();
-            const int nc = sh.nc;
-            __syncthreads();  // everyone has read nc before anyone pushes again
-            const bool last = base + step >= n;
-            if (!(last || nc + step > ccap)) continue;  // keep filling (uniform decision)
-            if (nc > 0) {
-                // ---- C: counting sort of the candidates by second-axis bin ----
-                zstart[t] = 0;
-                if (t == 0) zstart[kSlabZBins] = 0;
-                __syncthreads();
-                for (int c = t; c < nc; c += kSlabThreads) {
-                    const float4 v = cand[c];
-                    atomicAdd(&zstart[zbin(zx == 0 ? v.x : (zx == 1 ? v.y : v.z))], 1);
-                }
-                __syncthreads();
-                const int zc = zstart[t];
-                const int zoff = block_exclusive_scan(zc, sh.wsum, nullptr);
-                zstart[t] = zoff;                 // start of bin t
-                if (t == kSlabThreads - 1) zstart[kSlabZBins] = zoff + zc;
-                __syncthreads();
-                for (int c = t; c < nc; c += kSlabThreads) {
-                    const float4 v = cand[c];
-                    perm[atomicAdd(&zstart[zbin(zx == 0 ? v.x : (zx == 1 ? v.y : v.z))], 1)] = c;
-                }
-                __syncthreads();
-                // zstart[b] now holds the END of bin b == start of bin b+1; start of bin 0 is 0
-                // ---- D: one thread per query ----
-                for (int q = t; q < nq; q += kSlabThreads) {
-                    const float4 qq = qbuf[q];
+            const int zc = zstart[t];
+            const int zoff = block_exclusive_scan(zc, sh.wsum, nullptr);
+            zstart[t] = zoff;  // start of bin t
+            __syncthreads();
+            for (int c = t; c < nc; c += kSlabThreads) {
+                const float4 v = cand[c];
+                sorted[atomicAdd(&zstart[zbin(zx == 0 ? v.x : (zx == 1 ? v.y : v.z))], 1)] = v;
+            }
+            __syncthreads();
+            // zstart[b] now holds the END of bin b == start of bin b+1; start of bin 0 is 0
+            // D: kSlabG lanes per query; the group's lane 0 owns the sorted row
+            const int sub = t & (kSlabG - 1);
+            const int gbase = lane & ~(kSlabG - 1);
+            for (int q0 = 0; q0 < nq; q0 += kSlabThreads / kSlabG) {
+                const int q = q0 + (t / kSlabG);
+                const bool live = q < nq;
+                float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
+                int i0 = 0, i1 = 0;
+                if (live) {
+                    qq = qbuf[q];
                     const int bq = zbin(zx == 0 ? qq.x : (zx == 1 ? qq.y : qq.z));
-                    const int i0 = bq >= 2 ? zstart[bq - 2] : 0;                       // start of bin bq-1
-                    const int i1 = zstart[bq + 1 > kSlabZBins - 1 ? kSlabZBins - 1 : bq + 1];  // end of bin bq+1
-                    int *row = rows + q * rs;
-                    int total = hits[q];
-                    int len = total < nsample ? total : nsample;
-                    for (int i = i0; i < i1; ++i) {
-                        const float4 c = cand[perm[i]];
+                    i0 = bq >= 2 ? zstart[bq - 2] : 0;                                          // start of bin bq-1
+                    i1 = zstart[bq + 1 > kSlabZBins - 1 ? kSlabZBins - 1 : bq + 1];           // end of bin bq+1
+                }
+                const int iters = static_cast<int>(wave_max_u32(static_cast<unsigned>((i1 - i0 + kSlabG - 1) / kSlabG)));
+                int *row = rows + q * rs;
+                int total = 0, len = 0;
+                if (live && sub == 0) { total = hits[q]; len = total < nsample ? total : nsample; }
+                for (int it = 0; it < iters; ++it) {
+                    const int i = i0 + it * kSlabG + sub;
+                    bool hit = false;
+                    int k = 0;
+                    if (i < i1) {
+                        const float4 c = sorted[i];
                         const float dx = qq.x - c.x, dy = qq.y - c.y, dz = qq.z - c.z;
                         const float s2 = dx * dx + dy * dy + dz * dz;
-                        if (s2 < thresh) {
-                            const int k = __float_as_int(c.w);
+                        hit = s2 < thresh;
+                        k = __float_as_int(c.w);
+                    }
+                    const unsigned long long bal = __ballot(hit);
+                    if (bal == 0ull) continue;  // wave-uniform
+                    if (hit) stage[t] = k;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (sub == 0) {
+                        unsigned bits = static_cast<unsigned>(bal >> gbase) & ((1u << kSlabG) - 1u);
+                        while (bits) {
+                            const int src = __builtin_ctz(bits);
+                            bits &= bits - 1u;
+                            const int kk = stage[t + src];
                             ++total;
-                            if (len < nsample || k < row[len - 1]) {
+                            if (len < nsample || kk < row[len - 1]) {
                                 int pos = len < nsample ? len++ : len - 1;
-                                while (pos > 0 && row[pos - 1] > k) { row[pos] = row[pos - 1]; --pos; }
-                                row[pos] = k;
+                                while (pos > 0 && row[pos - 1] > kk) { row[pos] = row[pos - 1]; --pos; }
+                                row[pos] = kk;
                             }
                         }
                     }
-                    hits[q] = total;
+                    __builtin_amdgcn_wave_barrier();
                 }
+                if (live && sub == 0) hits[q] = total;
             }
             __syncthreads();
-            if (t == 0) sh.nc = 0;
-            __syncthreads();
-            if (last) break;
+        };
+
+        // ---------------- B: stream the data points through registers ----------------
+        int nc = 0;  // candidates in the LDS buffer: every thread tracks the same value
+        for (int base = 0; base < n; base += kSlabPPT * kSlabThreads) {
+            float px[kSlabPPT], py[kSlabPPT], pz[kSlabPPT];
+#pragma unroll
+            for (int u = 0; u < kSlabPPT; ++u) {
+                const int k = base + u * kSlabThreads + t;
+                const int kk = k < n ? k : 0;
+                px[u] = p1[kk * 3 + 0]; py[u] = p1[kk * 3 + 1]; pz[u] = p1[kk * 3 + 2];
+            }
+            unsigned inmask = 0;
+#pragma unroll
+            for (int u = 0; u < kSlabPPT; ++u) {
+                const int k = base + u * kSlabThreads + t;
+                const bool in = k < n && px[u] >= blo[0] && px[u] <= bhi[0] && py[u] >= blo[1] && py[u] <= bhi[1] &&
+                                pz[u] >= blo[2] && pz[u] <= bhi[2];
+                inmask |= (in ? 1u : 0u) << u;
+            }
+            int tot;
+            const int off = block_exclusive_scan(__builtin_popcount(inmask), sh.wsum, &tot);
+            if (nc + tot <= ccap) {
+                // common case: everything fits, positions from the scan (no atomics)
+                int pos = nc + off;
+#pragma unroll
+                for (int u = 0; u < kSlabPPT; ++u)
+                    if ((inmask >> u) & 1u)
+                        cand[pos++] = make_float4(px[u], py[u], pz[u], __int_as_float(base + u * kSlabThreads + t));
+                nc += tot;
+            } else {
+                // dense data: push one register slot at a time, flushing whenever the next slot might not fit
+#pragma unroll 1
+                for (int u = 0; u < kSlabPPT; ++u) {
+                    if (nc + kSlabThreads > ccap) {
+                        __syncthreads();
+                        flush(nc);
+                        nc = 0;
+                    }
+                    const int bit = (inmask >> u) & 1u;
+                    int tu;
+                    const int ou = block_exclusive_scan(bit, sh.wsum, &tu);
+                    float x = 0.f, y = 0.f, z = 0.f;
+#pragma unroll
+                    for (int v = 0; v < kSlabPPT; ++v)
+                        if (v == u) { x = px[v]; y = py[v]; z = pz[v]; }
+                    if (bit) cand[nc + ou] = make_float4(x, y, z, __int_as_float(base + u * kSlabThreads + t));
+                    nc += tu;
+                }
+            }
         }
+        __syncthreads();
+        if (stop == 3) return;
+        if (nc > 0) flush(nc);
+        if (stop == 5) return;
 
         // ---------------- E: write this round's rows ----------------
         for (int q = t; q < nq; q += kSlabThreads) {
@@ -398,16 +475,37 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
             }
         }
         if (GROUP) {
-            for (int e = t; e < total_e * 3; e += kSlabThreads) {
-                const int qc = e / 3, d = e - qc * 3;
-                const int q = qc / nsample, c = qc - q * nsample;
-                const float4 qq = qbuf[q];
-                const int j = __float_as_int(qq.w);
-                const int h = min(hits[q], nsample);
-                const int k = h == 0 ? 0 : rows[q * rs + (c < h ? c : 0)];
-                float v = p1[k * 3 + d];
-                if (center) v = v - (d == 0 ? qq.x : (d == 1 ? qq.y : qq.z));
-                grouped[((static_cast<size_t>(bb) * m + j) * nsample + c) * 3 + d] = v;
+            // one (query, slot) pair per lane: a 12-byte gather from the cloud, a 12-byte store into the
+            // row; consecutive lanes write consecutive triples.  U pairs in flight per thread.
+            constexpr int U = 4;
+            typedef float f3 __attribute__((ext_vector_type(3)));
+            for (int e0 = t; e0 < total_e; e0 += kSlabThreads * U) {
+                f3 v[U];
+                f3 cq[U];
+                size_t dst[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + u * kSlabThreads;
+                    const int ee = e < total_e ? e : 0;
+                    const int q = ee / nsample, c = ee - q * nsample;
+                    const float4 qq = qbuf[q];
+                    const int j = __float_as_int(qq.w);
+                    const int h = min(hits[q], nsample);
+                    const int k = h == 0 ? 0 : rows[q * rs + (c < h ? c : 0)];
+                    const float *src = p1 + static_cast<size_t>(k) * 3;
+                    v[u] = f3{ src[0], src[1], src[2] };
+                    cq[u] = f3{ qq.x, qq.y, qq.z };
+                    dst[u] = ((static_cast<size_t>(bb) * m + j) * nsample + c) * 3;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (e0 + u * kSlabThreads < total_e) {
+                        f3 o = v[u];
+                        if (center) o = o - cq[u];
+                        float *g = grouped + dst[u];
+                        g[0] = o.x; g[1] = o.y; g[2] = o.z;
+                    }
+                }
             }
         }
         __syncthreads();  // qbuf / rows / hits reused by the next round
@@ -488,8 +586,8 @@ static int grid_for(long long work_items, int block)
 
 static size_t slab_lds_bytes(int nsample, int qcap, int ccap)
 {
-    return 128 + sizeof(int) * (kSlabBins + kSlabZBins + 4) + sizeof(float4) * (static_cast<size_t>(qcap) + ccap) +
-           sizeof(int) * (static_cast<size_t>(ccap) + static_cast<size_t>(qcap) * (nsample | 1) + qcap);
+    return 128 + sizeof(int) * (kSlabBins + kSlabZBins + 4) + sizeof(float4) * (static_cast<size_t>(qcap) + 2 * ccap) +
+           sizeof(int) * (static_cast<size_t>(qcap) * (nsample | 1) + qcap + kSlabThreads);
 }
 
 static int launch_ball_query_bruteforce(int b, int n, int m, float thresh, int nsample, const float *xyz1,
@@ -516,6 +614,12 @@ static int launch_ball_query_bruteforce(int b, int n, int m, float thresh, int n
 }
 
 // HF_BALL_QUERY=bruteforce forces the fallback kernel (used by the tests to cover both paths)
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && e[0] ? atoi(e) : dflt;
+}
+
 static bool force_bruteforce()
 {
     const char *e = getenv("HF_BALL_QUERY");
@@ -528,29 +632,31 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
     const float thresh = ball_threshold(radius);
     // slab kernel geometry: LDS rows hold nsample ints per query
     int qcap, ccap;
-    if (nsample <= 32) { qcap = 256; ccap = 4096; }
-    else if (nsample <= 64) { qcap = 256; ccap = 2560; }
-    else if (nsample <= 128) { qcap = 128; ccap = 2560; }
+    if (nsample <= 32) { qcap = 256; ccap = 3072; }
+    else if (nsample <= 64) { qcap = 256; ccap = 2048; }
+    else if (nsample <= 128) { qcap = 128; ccap = 2048; }
     else { qcap = 0; ccap = 0; }
     const bool finite_r = radius < 3.0e18f;  // padded boxes stay finite
-    if (qcap == 0 || !finite_r || force_bruteforce() || b > 65535)
+    if (qcap == 0 || !finite_r || force_bruteforce() || b > 65535 || static_cast<long long>(m) * kNumCU > 0x7fffffffLL)
         return launch_ball_query_bruteforce(b, n, m, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
     // one workgroup per CU across the batch, at least ~64 queries per slab
     int nslab = kNumCU / b;
     if (nslab > m / 64) nslab = m / 64;
     if (nslab < 1) nslab = 1;
+    nslab = env_int("HF_QBP_SLABS", nslab);      // diagnostics only
+    const int stop = env_int("HF_QBP_STOP", 0);  // diagnostics only: early exit after phase N (outputs invalid)
     const size_t lds = slab_lds_bytes(nsample, qcap, ccap);
     dim3 grid(nslab, b);
     if (grouped) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         hipLaunchKernelGGL((qbp_slab_kernel<true>), grid, dim3(kSlabThreads), lds, st, n, m, nslab, radius, thresh,
-                           nsample, qcap, ccap, xyz1, xyz2, center, idx, pts_cnt, grouped);
+                           nsample, qcap, ccap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         hipLaunchKernelGGL((qbp_slab_kernel<false>), grid, dim3(kSlabThreads), lds, st, n, m, nslab, radius, thresh,
-                           nsample, qcap, ccap, xyz1, xyz2, center, idx, pts_cnt, grouped);
+                           nsample, qcap, ccap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped);
     }
     return launch_status();
 }
