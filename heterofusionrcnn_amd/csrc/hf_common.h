@@ -76,6 +76,40 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return min(min(a, b), min(c, d));
 }
 
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
+}
+__device__ __forceinline__ float ord2f(unsigned o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// exclusive prefix sum of one int per thread over a 1024-thread workgroup; `wsum` = 16 ints of LDS
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int x = wsum[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();  // wsum reusable
+    if (total) *total = tot;
+    return base + inc - v;
+}
+
 __device__ __forceinline__ int lane_id() { return static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }
 
 // number of set bits of `mask` below this lane

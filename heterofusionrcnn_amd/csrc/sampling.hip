@@ -14,6 +14,9 @@
 //     an explicit tie key, so the result does not depend on this kernel's own layout.
 // The op is latency/VALU-bound on one CU per cloud (m-1 strictly sequential rounds), not
 // HBM-bound; DESIGN.md reports us/round.
+#include <math.h>
+#include <stdlib.h>
+
 #include "hf_common.h"
 
 namespace hf {
@@ -21,11 +24,10 @@ namespace hf {
 // smaller key wins a distance tie
 __device__ __forceinline__ unsigned fps_tiekey(int k) { return (static_cast<unsigned>(k & 511) << 22) | static_cast<unsigned>(k >> 9); }
 
-constexpr int kFpsThreads = 1024;
-constexpr int kFpsWaves = kFpsThreads / kWave;
-constexpr int kFpsMaxPPT = 16;
+constexpr int kFpsMaxPoints = 16384;  // on-chip limit: points held in registers
+constexpr int kFpsMaxWaves = 16;
 
-struct FpsSlot {
+struct __attribute__((aligned(32))) FpsSlot {
     int dist;   // float bits of the wave's best running distance (>= 0), -1 = no valid point
     int k;      // its point index
     float x, y, z;
@@ -39,25 +41,59 @@ template <> __device__ __forceinline__ float vec_get<1>(const float &v, int) { r
 template <int N> __device__ __forceinline__ void vec_set(typename FpsVec<N>::type &v, int i, float f) { v[i] = f; }
 template <> __device__ __forceinline__ void vec_set<1>(float &v, int, float f) { v = f; }
 
-// block-level pick among the 16 per-wave slots; every lane of every wave computes the same winner.
-// lanes replicate slot (lane & 15) in each DPP row, so 4-step row reductions suffice.
-__device__ __forceinline__ int fps_pick_slot(const FpsSlot *slots, int lane)
+// block-level pick among the per-wave slots; every wave computes the same winner.  Lanes replicate
+// slot (lane & (NW-1)) in each DPP row, so 4-step row reductions suffice; the winner's record is then
+// taken from the winning lane's registers (v_readlane) instead of a second, dependent LDS read.  The
+// tie-key reduction only runs when two waves really post the same distance.
+struct FpsPick { int k; float x, y, z; };
+
+template <int NW>
+__device__ __forceinline__ FpsPick fps_pick_slot(const FpsSlot *slots, int lane)
 {
-    const int sl = lane & (kFpsWaves - 1);
-    const int sd = slots[sl].dist;
-    const int sk = slots[sl].k;
+    const int sl = lane & (NW - 1);
+    const int4 head = *reinterpret_cast<const int4 *>(&slots[sl]);  // dist, k, x, y
+    const float sz = slots[sl].z;
+    const int sd = head.x, sk = head.y;
     const unsigned gbest = row_max_u32(static_cast<unsigned>(sd + 1));
-    const unsigned key = static_cast<unsigned>(sd + 1) == gbest ? fps_tiekey(sk) : 0xffffffffu;
-    const unsigned gkey = row_min_u32(key);
-    const unsigned long long win = __ballot(key == gkey);
-    return __builtin_ctzll(win) & (kFpsWaves - 1);
+    unsigned long long win = __ballot(static_cast<unsigned>(sd + 1) == gbest) & ((1ull << NW) - 1ull);
+    if (__builtin_popcountll(win) > 1) {  // wave-uniform, rare: exact distance tie between waves
+        const unsigned key = static_cast<unsigned>(sd + 1) == gbest ? fps_tiekey(sk) : 0xffffffffu;
+        const unsigned gkey = row_min_u32(key);
+        win = __ballot(key == gkey) & ((1ull << NW) - 1ull);
+    }
+    const int wl = __builtin_ctzll(win);
+    FpsPick r;
+    r.k = __builtin_amdgcn_readlane(sk, wl);
+    r.x = __int_as_float(__builtin_amdgcn_readlane(head.z, wl));
+    r.y = __int_as_float(__builtin_amdgcn_readlane(head.w, wl));
+    r.z = readlane_f(sz, wl);
+    return r;
 }
 
-template <int PPT, bool FULL>
-__global__ __launch_bounds__(kFpsThreads) void fps_onchip_kernel(int n, int m, const float *__restrict__ xyz,
-                                                                 int *__restrict__ out)
+// slot i of thread t holds point fps_slot_point<PPT,NT>(t,i).  Inside a thread the slots are ordered by
+// (k mod 512, k) so that "first slot wins" is the reference's tie rule: with NT >= 512 every slot of a
+// thread shares k mod 512; with NT = 256 the first half of the slots has residue t, the second t+256.
+template <int PPT, int NT>
+__device__ __forceinline__ int fps_slot_point(int t, int i)
 {
+    if constexpr (NT >= 512 || PPT == 1) {
+        return t + i * NT;
+    } else {
+        static_assert(NT == 256 && PPT % 2 == 0, "slot order implemented for 256-thread workgroups");
+        constexpr int H = PPT / 2;
+        return t + 256 * (i / H) + 512 * (i % H);
+    }
+}
+
+template <int PPT, int NT>
+__global__ __launch_bounds__(NT) void fps_onchip_kernel(int n, int m, const float *__restrict__ xyz,
+                                                        int *__restrict__ out)
+{
+    constexpr int kFpsWaves = NT / 64;
     __shared__ FpsSlot slots[2][kFpsWaves];
+    // the sampled indices are staged in LDS and written out once at the end: a global store per round
+    // would make every round's s_barrier wait for its vmcnt(0) (an L2 round trip on the critical path)
+    __shared__ unsigned short picked[PPT * NT];
     typedef typename FpsVec<PPT>::type vec_t;
 
     const int t = threadIdx.x;
@@ -67,61 +103,279 @@ __global__ __launch_bounds__(kFpsThreads) void fps_onchip_kernel(int n, int m, c
 
     // x/y/z as ext vectors: a wave-uniform dynamic index lowers to s_set_gpr_idx (no scratch)
     vec_t x, y, z;
-    int td[PPT];  // running min distance as float bits; all values >= +0 so int order == float order
+    int td[PPT];  // running min distance as float bits (>= +0: int order == float order); -1 = no point
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int k = t + i * kFpsThreads;
-        const int kk = (FULL || k < n) ? k : 0;
+        const int k = fps_slot_point<PPT, NT>(t, i);
+        const bool ok = k < n;
+        const int kk = ok ? k : 0;
         vec_set<PPT>(x, i, pts[kk * 3 + 0]);
         vec_set<PPT>(y, i, pts[kk * 3 + 1]);
         vec_set<PPT>(z, i, pts[kk * 3 + 2]);
-        td[i] = __float_as_int(1e38f);
+        td[i] = ok ? __float_as_int(1e38f) : -1;  // min() keeps -1 forever; -1 never beats a real point
     }
-    int nvalid = PPT;  // slots [0,nvalid) of this thread hold real points
-    if (!FULL) nvalid = t < n ? (n - 1 - t) / kFpsThreads + 1 : 0;
 
     float x1 = pts[0], y1 = pts[1], z1 = pts[2];
-    if (t == 0) o[0] = 0;
+    const int mm = m < PPT * NT ? m : PPT * NT;  // rounds beyond n only repeat point 0 (all distances are 0)
+    if (t == 0) picked[0] = 0;
 
-    for (int j = 1; j < m; ++j) {
+    for (int j = 1; j < mm; ++j) {
         int best = -1, bi = 0;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const float dx = vec_get<PPT>(x, i) - x1, dy = vec_get<PPT>(y, i) - y1, dz = vec_get<PPT>(z, i) - z1;
             const float d = dx * dx + dy * dy + dz * dz;
-            int s = min(__float_as_int(d), td[i]);  // == fminf on non-negative floats
+            const int s = min(__float_as_int(d), td[i]);  // == fminf on non-negative floats
             td[i] = s;
-            if (!FULL) s = i < nvalid ? s : -1;
-            if (s > best) { best = s; bi = i; }  // strict: the smallest k wins inside a thread
+            if (s > best) { best = s; bi = i; }  // strict: the first slot in (k mod 512, k) order wins
         }
-        // wave arg-max; among equal lanes the lowest lane has the smallest (k mod 512)
+        // wave arg-max; an exact tie between lanes (rare) is resolved with the explicit tie key
         const int wbest = static_cast<int>(wave_max_u32(static_cast<unsigned>(best + 1))) - 1;
-        const unsigned long long tied = __ballot(best == wbest);
+        unsigned long long tied = __ballot(best == wbest);
+        if (__builtin_popcountll(tied) > 1) {
+            const unsigned key = best == wbest ? fps_tiekey(fps_slot_point<PPT, NT>(t, bi)) : 0xffffffffu;
+            const unsigned kmin = wave_min_u32(key);
+            tied = __ballot(key == kmin);
+        }
         const int wl = __builtin_ctzll(tied);
         const int wi = __builtin_amdgcn_readlane(bi, wl);
         const float cx = vec_get<PPT>(x, wi), cy = vec_get<PPT>(y, wi), cz = vec_get<PPT>(z, wi);
         FpsSlot *cur = slots[j & 1];
         if (lane == wl) {
             cur[wave].dist = wbest;
-            cur[wave].k = t + wi * kFpsThreads;
+            cur[wave].k = fps_slot_point<PPT, NT>(t, wi);
             cur[wave].x = cx;
             cur[wave].y = cy;
             cur[wave].z = cz;
         }
         __syncthreads();
-        const int ws = fps_pick_slot(cur, lane);
-        x1 = cur[ws].x;
-        y1 = cur[ws].y;
-        z1 = cur[ws].z;
-        if (t == 0) o[j] = cur[ws].k;
+        const FpsPick w = fps_pick_slot<kFpsWaves>(cur, lane);
+        x1 = w.x;
+        y1 = w.y;
+        z1 = w.z;
+        if (t == 0) picked[j] = static_cast<unsigned short>(w.k);
     }
+    __syncthreads();
+    for (int j = t; j < m; j += NT) o[j] = j < mm ? picked[j] : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Bucketed FPS (main path for larger clouds).  Same arithmetic, same winner every round; the
+// difference is which points get touched.
+//
+// A new sample p only lowers the running distance of points closer to p than their current value.
+// Late in the sampling that is a small neighbourhood, yet the plain kernel above updates all n
+// points every round.  Here the cloud is first counting-sorted by Morton cell (prologue, in LDS)
+// so that every (wave, slot) pair holds a spatially compact BUCKET of 64 points with a bounding
+// box and a cached maximum running distance.  Per round, lanes 0..PPT-1 of each wave test their
+// wave's PPT buckets at once:  if  dist2(p, bbox) * 0.99999 > bucket_max  every point of the bucket
+// has d >= its running distance, min(d, td) is a no-op and the bucket is skipped -- exactly.
+// (fp32: each computed d is >= the computed box bound * (1 - 8 ulp); 0.99999 leaves 40x slack.)
+// Only touched buckets recompute their maximum; a wave whose buckets were all skipped re-posts
+// its cached candidate.  The block-level pick and the tie rule are those of the plain kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kFpsCellBits = 12;
+constexpr int kFpsCells = 1 << kFpsCellBits;
+
+struct FpsBucketShared {
+    unsigned bmin[3], bmax[3];
+    int wsum[kFpsMaxWaves];
+    FpsSlot slots[2][kFpsMaxWaves];
+};
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_bucket_kernel(int n, int m, const float *__restrict__ xyz,
+                                                          int *__restrict__ out)
+{
+    constexpr int kFpsThreads = 1024, kFpsWaves = 16;
+    __shared__ FpsBucketShared sh;
+    __shared__ int cellstart[kFpsCells];
+    __shared__ unsigned short order[kFpsThreads * PPT];   // sorted position -> original point index
+    __shared__ unsigned short picked[kFpsThreads * PPT];  // sampled indices, written out once at the end
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const float *pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
+    int *o = out + static_cast<size_t>(blockIdx.x) * m;
+
+    // ---------------- prologue 1: bounding box, cell of every point ----------------
+    if (t < 3) { sh.bmin[t] = 0xffffffffu; sh.bmax[t] = 0u; }
+    for (int c = t; c < kFpsCells; c += kFpsThreads) cellstart[c] = 0;
+    __syncthreads();
+    {
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int k = t; k < n; k += kFpsThreads) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = pts[k * 3 + d];
+                lo[d] = fminf(lo[d], v);
+                hi[d] = fmaxf(hi[d], v);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const unsigned a = wave_min_u32(f2ord(lo[d]));
+            const unsigned b = wave_max_u32(f2ord(hi[d]));
+            if (lane == 0) { atomicMin(&sh.bmin[d], a); atomicMax(&sh.bmax[d], b); }
+        }
+    }
+    __syncthreads();
+    float glo[3], gext[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { glo[d] = ord2f(sh.bmin[d]); gext[d] = ord2f(sh.bmax[d]) - glo[d]; }
+    // split the 12 cell bits over the axes so that cells are as cubic as possible
+    int bits[3] = { 0, 0, 0 };
+    {
+        float cs[3] = { gext[0], gext[1], gext[2] };
+        for (int b = 0; b < kFpsCellBits; ++b) {
+            int d = 0;
+            if (cs[1] > cs[d]) d = 1;
+            if (cs[2] > cs[d]) d = 2;
+            if (d == 0) { bits[0]++; cs[0] *= 0.5f; } else if (d == 1) { bits[1]++; cs[1] *= 0.5f; } else { bits[2]++; cs[2] *= 0.5f; }
+        }
+    }
+    float cscale[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) cscale[d] = gext[d] > 0.0f ? static_cast<float>(1 << bits[d]) / gext[d] : 0.0f;
+    auto cell_of = [&](float px, float py, float pz) -> int {
+        int c[3];
+        const float v[3] = { px, py, pz };
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            int q = static_cast<int>((v[d] - glo[d]) * cscale[d]);
+            const int top = (1 << bits[d]) - 1;
+            c[d] = q < 0 ? 0 : (q > top ? top : q);
+        }
+        // generalised Morton interleave (axes drop out when their bits run out)
+        int code = 0, pos = 0;
+        for (int b = 0; b < kFpsCellBits; ++b) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if (b < bits[d]) { code |= ((c[d] >> b) & 1) << pos; ++pos; }
+        }
+        return code;
+    };
+    for (int k = t; k < n; k += kFpsThreads) atomicAdd(&cellstart[cell_of(pts[k * 3], pts[k * 3 + 1], pts[k * 3 + 2])], 1);
+    __syncthreads();
+    // ---------------- prologue 2: scan the cells, scatter the point indices ----------------
+    {
+        constexpr int CPT = kFpsCells / kFpsThreads;
+        int c[CPT], sum = 0;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) { c[u] = cellstart[t * CPT + u]; sum += c[u]; }
+        int run = block_exclusive_scan(sum, sh.wsum, nullptr);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) { cellstart[t * CPT + u] = run; run += c[u]; }
+    }
+    __syncthreads();
+    for (int k = t; k < n; k += kFpsThreads) {
+        const int pos = atomicAdd(&cellstart[cell_of(pts[k * 3], pts[k * 3 + 1], pts[k * 3 + 2])], 1);
+        order[pos] = static_cast<unsigned short>(k);
+    }
+    __syncthreads();
+
+    // ---------------- prologue 3: load the buckets; bucket g = i*16 + wave sits in slot i of this wave ----------------
+    float x[PPT], y[PPT], z[PPT];
+    int td[PPT];
+    // lane i (< PPT) keeps the box and the maximum running distance of bucket i
+    float bx0 = 0.f, bx1 = 0.f, by0 = 0.f, by1 = 0.f, bz0 = 0.f, bz1 = 0.f;
+    int bmaxv = -1;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = (i * kFpsWaves + wave) * 64 + lane;
+        const bool ok = p < n;
+        const int k = ok ? order[p] : 0;
+        x[i] = pts[k * 3 + 0];
+        y[i] = pts[k * 3 + 1];
+        z[i] = pts[k * 3 + 2];
+        td[i] = ok ? __float_as_int(1e38f) : -1;  // -1 is never raised by min(), never wins
+        const unsigned lx = wave_min_u32(ok ? f2ord(x[i]) : 0xffffffffu), hx = wave_max_u32(ok ? f2ord(x[i]) : 0u);
+        const unsigned ly = wave_min_u32(ok ? f2ord(y[i]) : 0xffffffffu), hy = wave_max_u32(ok ? f2ord(y[i]) : 0u);
+        const unsigned lz = wave_min_u32(ok ? f2ord(z[i]) : 0xffffffffu), hz = wave_max_u32(ok ? f2ord(z[i]) : 0u);
+        const bool any = __ballot(ok) != 0ull;
+        if (lane == i) {
+            bx0 = ord2f(lx); bx1 = ord2f(hx); by0 = ord2f(ly); by1 = ord2f(hy); bz0 = ord2f(lz); bz1 = ord2f(hz);
+            bmaxv = any ? __float_as_int(1e38f) : -1;
+        }
+    }
+
+    float x1 = pts[0], y1 = pts[1], z1 = pts[2];
+    const int mm = m < kFpsThreads * PPT ? m : kFpsThreads * PPT;
+    if (t == 0) picked[0] = 0;
+    // this wave's current candidate (wave-uniform values)
+    int c_dist = -1, c_k = 0;
+    float c_x = 0.f, c_y = 0.f, c_z = 0.f;
+
+    for (int j = 1; j < mm; ++j) {
+        // ---- which of my wave's buckets can change? (lanes 0..PPT-1, one bucket each) ----
+        const float ex = fmaxf(fmaxf(bx0 - x1, x1 - bx1), 0.0f);
+        const float ey = fmaxf(fmaxf(by0 - y1, y1 - by1), 0.0f);
+        const float ez = fmaxf(fmaxf(bz0 - z1, z1 - bz1), 0.0f);
+        const float lb = ex * ex + ey * ey + ez * ez;
+        const bool need = bmaxv >= 0 && !(lb * 0.99999f > __int_as_float(bmaxv));
+        const unsigned mask = static_cast<unsigned>(__ballot(need));
+        if (mask != 0u) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                if ((mask >> i) & 1u) {
+                    const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
+                    const float d = dx * dx + dy * dy + dz * dz;
+                    const int s = min(__float_as_int(d), td[i]);
+                    td[i] = s;
+                    const int nb = static_cast<int>(wave_max_u32(static_cast<unsigned>(s + 1))) - 1;
+                    if (lane == i) bmaxv = nb;
+                }
+            }
+            // ---- this wave's best point: max distance, then the reference's tie key ----
+            const int wbest = static_cast<int>(wave_max_u32(static_cast<unsigned>(bmaxv + 1))) - 1;
+            c_dist = wbest;
+            if (wbest >= 0) {
+                const unsigned eq = static_cast<unsigned>(__ballot(bmaxv == wbest));
+                unsigned bestkey = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < PPT; ++i) {
+                    if ((eq >> i) & 1u) {
+                        const bool match = td[i] == wbest;
+                        const int korig = order[(i * kFpsWaves + wave) * 64 + lane];
+                        const unsigned key = match ? fps_tiekey(korig) : 0xffffffffu;
+                        const unsigned kmin = wave_min_u32(key);
+                        if (kmin < bestkey) {
+                            bestkey = kmin;
+                            const int L = __builtin_ctzll(__ballot(key == kmin));
+                            c_k = __builtin_amdgcn_readlane(korig, L);
+                            c_x = readlane_f(x[i], L);
+                            c_y = readlane_f(y[i], L);
+                            c_z = readlane_f(z[i], L);
+                        }
+                    }
+                }
+            }
+        }
+        FpsSlot *cur = sh.slots[j & 1];
+        if (lane == 0) {
+            cur[wave].dist = c_dist;
+            cur[wave].k = c_k;
+            cur[wave].x = c_x;
+            cur[wave].y = c_y;
+            cur[wave].z = c_z;
+        }
+        __syncthreads();
+        const FpsPick w = fps_pick_slot<kFpsWaves>(cur, lane);
+        x1 = w.x;
+        y1 = w.y;
+        z1 = w.z;
+        if (t == 0) picked[j] = static_cast<unsigned short>(w.k);
+    }
+    __syncthreads();
+    for (int j = t; j < m; j += kFpsThreads) o[j] = j < mm ? picked[j] : 0;
 }
 
 // Fallback for clouds larger than the on-chip limit: running distances in caller scratch
 // (b,n) floats, points re-read from global (L2-resident).  Same selection rule.
-__global__ __launch_bounds__(kFpsThreads) void fps_scratch_kernel(int n, int m, const float *__restrict__ xyz,
-                                                                  float *__restrict__ temp, int *__restrict__ out)
+__global__ __launch_bounds__(1024) void fps_scratch_kernel(int n, int m, const float *__restrict__ xyz,
+                                                           float *__restrict__ temp, int *__restrict__ out)
 {
+    constexpr int kFpsThreads = 1024, kFpsWaves = 16;
     __shared__ FpsSlot slots[2][kFpsWaves];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -155,11 +409,11 @@ __global__ __launch_bounds__(kFpsThreads) void fps_scratch_kernel(int n, int m, 
             slots[par][wave].z = bz;
         }
         __syncthreads();
-        const int ws = fps_pick_slot(slots[par], lane);
-        const int old = slots[par][ws].k;
-        x1 = slots[par][ws].x;
-        y1 = slots[par][ws].y;
-        z1 = slots[par][ws].z;
+        const FpsPick w = fps_pick_slot<kFpsWaves>(slots[par], lane);
+        const int old = w.k;
+        x1 = w.x;
+        y1 = w.y;
+        z1 = w.z;
         if (t == 0) o[j] = old;
     }
 }
@@ -194,20 +448,74 @@ __global__ void gather_point_grad_kernel(int n, int m, long long total, const fl
 }
 
 template <int PPT>
+static int launch_fps_bucket(int b, int n, int m, const float *inp, int *out, hipStream_t st)
+{
+    hipLaunchKernelGGL((fps_bucket_kernel<PPT>), dim3(b), dim3(1024), 0, st, n, m, inp, out);
+    return launch_status();
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && e[0] ? atoi(e) : dflt;
+}
+
+// HF_FPS=plain|bucket overrides the size heuristic (tests cover both kernels this way)
+static int fps_mode()
+{
+    const char *e = getenv("HF_FPS");
+    if (!e || !e[0]) return 0;
+    return e[0] == 'p' ? 1 : (e[0] == 'b' ? 2 : 0);
+}
+
+template <int PPT, int NT>
+static int launch_fps_plain(int b, int n, int m, const float *inp, int *out, hipStream_t st)
+{
+    hipLaunchKernelGGL((fps_onchip_kernel<PPT, NT>), dim3(b), dim3(NT), 0, st, n, m, inp, out);
+    return launch_status();
+}
+
+// plain kernel: NT threads, PPT = ceil(n / NT) rounded up to a power of two
+template <int NT>
+static int launch_fps_plain_nt(int b, int n, int m, const float *inp, int *out, hipStream_t st)
+{
+    const int ppt = div_up(n, NT);
+    if (ppt <= 1) return launch_fps_plain<1, NT>(b, n, m, inp, out, st);
+    if (ppt <= 2) return launch_fps_plain<2, NT>(b, n, m, inp, out, st);
+    if (ppt <= 4) return launch_fps_plain<4, NT>(b, n, m, inp, out, st);
+    if (ppt <= 8) return launch_fps_plain<8, NT>(b, n, m, inp, out, st);
+    if (ppt <= 16) return launch_fps_plain<16, NT>(b, n, m, inp, out, st);
+    if constexpr (NT <= 512) {
+        if (ppt <= 32) return launch_fps_plain<32, NT>(b, n, m, inp, out, st);
+    }
+    return HF_EINVAL;
+}
+
 static int launch_fps_onchip(int b, int n, int m, const float *inp, int *out, hipStream_t st)
 {
-    if (n == PPT * kFpsThreads)
-        hipLaunchKernelGGL((fps_onchip_kernel<PPT, true>), dim3(b), dim3(kFpsThreads), 0, st, n, m, inp, out);
-    else
-        hipLaunchKernelGGL((fps_onchip_kernel<PPT, false>), dim3(b), dim3(kFpsThreads), 0, st, n, m, inp, out);
-    return launch_status();
+    const int mode = fps_mode();
+    // bucket pruning pays once there are enough rounds to amortise its prologue
+    const bool bucket = mode == 2 || (mode == 0 && n >= 8192 && m >= 256);
+    if (bucket) {
+        const int ppt = div_up(n, 1024);
+        if (ppt <= 1) return launch_fps_bucket<1>(b, n, m, inp, out, st);
+        if (ppt <= 2) return launch_fps_bucket<2>(b, n, m, inp, out, st);
+        if (ppt <= 4) return launch_fps_bucket<4>(b, n, m, inp, out, st);
+        if (ppt <= 8) return launch_fps_bucket<8>(b, n, m, inp, out, st);
+        return launch_fps_bucket<16>(b, n, m, inp, out, st);
+    }
+    int nt = env_int("HF_FPS_THREADS", 0);  // diagnostics: force the workgroup size of the plain kernel
+    if (nt == 0) nt = n <= 4096 ? 256 : 512;  // fewer, fatter waves: measured faster at every size
+    if (nt == 256 && n <= 256 * 16) return launch_fps_plain_nt<256>(b, n, m, inp, out, st);
+    if (nt <= 512 && n <= 512 * 32) return launch_fps_plain_nt<512>(b, n, m, inp, out, st);
+    return launch_fps_plain_nt<1024>(b, n, m, inp, out, st);
 }
 
 }  // namespace hf
 
 using namespace hf;
 
-HF_API int hf_fps_onchip_limit(void) { return kFpsMaxPPT * kFpsThreads; }
+HF_API int hf_fps_onchip_limit(void) { return kFpsMaxPoints; }
 
 HF_API size_t hf_fps_workspace(int b, int n)
 {
@@ -221,14 +529,9 @@ HF_API int hf_farthest_point_sample(int b, int n, int m, const float *inp, float
     if (b < 0 || n <= 0 || m <= 0 || !inp || !out) return HF_EINVAL;
     if (b == 0) return HF_OK;
     hipStream_t st = as_stream(stream);
-    const int ppt = div_up(n, kFpsThreads);
-    if (ppt <= 1) return launch_fps_onchip<1>(b, n, m, inp, out, st);
-    if (ppt <= 2) return launch_fps_onchip<2>(b, n, m, inp, out, st);
-    if (ppt <= 4) return launch_fps_onchip<4>(b, n, m, inp, out, st);
-    if (ppt <= 8) return launch_fps_onchip<8>(b, n, m, inp, out, st);
-    if (ppt <= 16) return launch_fps_onchip<16>(b, n, m, inp, out, st);
+    if (n <= kFpsMaxPoints) return launch_fps_onchip(b, n, m, inp, out, st);
     if (!temp) return HF_EWORKSPACE;
-    hipLaunchKernelGGL(fps_scratch_kernel, dim3(b), dim3(kFpsThreads), 0, st, n, m, inp, temp, out);
+    hipLaunchKernelGGL(fps_scratch_kernel, dim3(b), dim3(1024), 0, st, n, m, inp, temp, out);
     return launch_status();
 }
 

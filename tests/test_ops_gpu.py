@@ -71,10 +71,25 @@ def test_golden_grouping(hf):
     assert np.array_equal(host(hf.group_point(dev(r["points"]), idx)), r["grouped"])
 
 
+def _fps_both_kernels(hf, m, xyz_dev):
+    """run the plain and the bucketed FPS kernel (HF_FPS override) and insist they agree"""
+    outs = []
+    for mode in ("plain", "bucket"):
+        os.environ["HF_FPS"] = mode
+        try:
+            outs.append(hf.farthest_point_sample(m, xyz_dev))
+        finally:
+            os.environ.pop("HF_FPS", None)
+    assert torch.equal(outs[0], outs[1]), "plain and bucketed FPS disagree"
+    auto = hf.farthest_point_sample(m, xyz_dev)
+    assert torch.equal(auto, outs[0])
+    return auto
+
+
 def test_golden_fps_gather(hf):
     g = load_golden("fps")
     for name, m in (("unit", 256), ("dup", 256), ("big", 1700), ("big2", 1400), ("tiny", 5)):
-        out = hf.farthest_point_sample(m, dev(g[name]))
+        out = _fps_both_kernels(hf, m, dev(g[name]))
         assert out.dtype == torch.int32
         assert np.array_equal(host(out), g[name + "_fps"]), name
     g = load_golden("gather")
@@ -223,21 +238,33 @@ def test_ball_threshold_boundary(hf, oracle_mod):
 
 
 @pytest.mark.parametrize("b,n,m", [(2, 1024, 300), (1, 1500, 1500), (3, 700, 64), (1, 4096, 700), (2, 3000, 500),
-                                   (1, 16384, 600), (1, 20000, 128), (2, 5, 5), (1, 1, 1)])
+                                   (1, 16384, 600), (1, 20000, 128), (2, 5, 5), (1, 1, 1), (2, 10, 25), (1, 3000, 3100)])
 def test_oracle_fps(hf, oracle_mod, b, n, m):
     rng = np.random.default_rng(n + m)
     xyz = kitti_uniform(rng, b, n)
     if n >= 1000:  # duplicated tail as in kitti_dataset.py:358-364 -> exact distance ties
         xyz[:, n - n // 10:] = xyz[:, :n // 10]
-    out = hf.farthest_point_sample(m, dev(xyz))
+    out = _fps_both_kernels(hf, m, dev(xyz)) if n <= 16384 else hf.farthest_point_sample(m, dev(xyz))
     assert np.array_equal(host(out), oracle_mod.farthest_point_sample(m, xyz))
+
+
+def test_oracle_fps_clustered(hf, oracle_mod):
+    """non-uniform cloud (dense blobs + sparse background + a flat ground plane): stresses the bucket skip test"""
+    rng = np.random.default_rng(12)
+    n = 8192
+    xyz = kitti_uniform(rng, 2, n)
+    xyz[:, :3000] = np.array([5.0, -1.0, 12.0], np.float32) + rng.normal(0, 0.5, (2, 3000, 3)).astype(np.float32)
+    xyz[:, 3000:5000, 1] = 1.7                      # ground plane
+    xyz[:, 5000:5200] = xyz[:, 0:200]               # duplicates
+    out = _fps_both_kernels(hf, 2048, dev(xyz))
+    assert np.array_equal(host(out), oracle_mod.farthest_point_sample(2048, xyz))
 
 
 def test_oracle_fps_degenerate(hf, oracle_mod):
     """all points identical / more samples than distinct points: every distance ties at 0"""
     xyz = np.ones((2, 2000, 3), np.float32)
     xyz[1, :7] = np.arange(21, dtype=np.float32).reshape(7, 3)
-    out = hf.farthest_point_sample(40, dev(xyz))
+    out = _fps_both_kernels(hf, 40, dev(xyz))
     assert np.array_equal(host(out), oracle_mod.farthest_point_sample(40, xyz))
 
 
