@@ -596,3 +596,77 @@ def test_runs_on_the_callers_stream(hf, oracle_mod):
     s.synchronize()
     oi, oc = oracle_mod.query_ball_point(0.1, 16, x1, x2)
     assert np.array_equal(host(idx), oi) and np.array_equal(host(fps), oracle_mod.farthest_point_sample(64, x1))
+
+
+# ------------------------------------------------------------------ callers: SA/FP modules, prefetch pipeline
+def test_stack_with_prefetched_geometry_matches_inline(hf):
+    from heterofusionrcnn_amd import modules
+    from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    sa = ((512, 2.0, 16, (16, 32)), (128, 4.0, 16, (32, 64)))
+    net = modules.PointnetSAFPStack(in_channel=1, sa=sa, fp=((64, 64), (32, 32))).cuda()
+    xyz = dev(kitti_uniform(rng, 2, 2048))
+    inten = dev(rng.uniform(-.5, .5, (2, 2048, 1)).astype(np.float32))
+    out_inline = net(xyz, inten)
+    pf = GeometryPrefetcher(net.geometry)
+    pf.submit(xyz)
+    geo = pf.get()
+    out_pre = net(xyz, inten, geometry=geo)
+    assert out_inline.shape == (2, 2048, 32)
+    assert torch.equal(out_inline, out_pre)
+    out_pre.mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_sa_module_composition_against_oracle(hf, oracle_mod):
+    """sample_and_group restated from pointnet_util.py:24-66: op order, centring, concat order [xyz, feats]"""
+    from heterofusionrcnn_amd import modules
+    rng = np.random.default_rng(1)
+    xyz = rng.random((2, 1024, 3), dtype=np.float32)
+    feats = rng.standard_normal((2, 1024, 5)).astype(np.float32)
+    new_xyz, new_points, idx, gxyz = modules.sample_and_group(128, 0.2, 16, dev(xyz), dev(feats))
+    o_fps = oracle_mod.farthest_point_sample(128, xyz)
+    o_new = oracle_mod.gather_point(xyz, o_fps)
+    o_idx, _ = oracle_mod.query_ball_point(0.2, 16, xyz, o_new)
+    o_gxyz = oracle_mod.group_point(xyz, o_idx) - o_new[:, :, None, :]
+    o_np = np.concatenate([o_gxyz, oracle_mod.group_point(feats, o_idx)], -1)
+    assert np.array_equal(host(new_xyz), o_new) and np.array_equal(host(idx), o_idx)
+    assert np.array_equal(host(gxyz), o_gxyz) and np.array_equal(host(new_points), o_np)
+    # MSG order is [feats, xyz] (pointnet_util.py:264)
+    msg = modules.PointnetSAModuleMSG(128, [0.2], [16], 5, [[8]], bn=False).cuda()
+    with torch.no_grad():
+        _, out = msg(dev(xyz), dev(feats))
+        w, b = msg.mlps[0][0].fc.weight, msg.mlps[0][0].fc.bias
+        want = torch.relu(dev(np.concatenate([oracle_mod.group_point(feats, o_idx), o_gxyz], -1)) @ w.t() + b).max(dim=2).values
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+
+
+def test_iou3d_and_nms_adapters(hf, oracle_mod):
+    """box3d_iou / oriented_nms_3d / sb_nms restated from compute_iou.py:23-80, model_util.py:101-142"""
+    from heterofusionrcnn_amd import modules
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import random_boxes3d, boxes3d_to_bev
+    rng = np.random.default_rng(2)
+    a = random_boxes3d(rng, 60)
+    a[30:] = a[:30] + rng.normal(0, 0.2, (30, 7)).astype(np.float32)
+    b = a[:20].copy()
+    i3, i2 = modules.box3d_iou(dev(a), dev(b))
+    ov, o2 = oracle_mod.compute_bev_iou(boxes3d_to_bev(a), boxes3d_to_bev(b))
+    np.testing.assert_allclose(host(i2), o2, atol=TOL)
+    h = np.clip(np.minimum(a[:, None, 1], b[None, :, 1]) - np.maximum(a[:, None, 1] - a[:, None, 5], b[None, :, 1] - b[None, :, 5]), 0, None)
+    va, vb = (a[:, 3] * a[:, 4] * a[:, 5])[:, None], (b[:, 3] * b[:, 4] * b[:, 5])[None]
+    np.testing.assert_allclose(host(i3), ov * h / np.clip(va + vb - ov * h, 1e-7, None), atol=2e-5)
+    np.testing.assert_allclose(np.diag(host(i3)[:20]), 1.0, atol=1e-4)
+    scores = rng.random(60).astype(np.float32)
+    order = np.argsort(-scores, kind="stable")
+    want = order[oracle_mod.oriented_nms(boxes3d_to_bev(a)[order], 0.1)]
+    got = modules.oriented_nms_3d(dev(a), dev(scores), 0.1)
+    assert np.array_equal(host(got), want)
+    ind, n = modules.sb_nms(dev(a), dev(scores), 0.1, 100, fixed_num_proposal_nms=False)
+    kept = oracle_mod.oriented_nms(boxes3d_to_bev(a)[order], 0.1, return_count=True)[1]
+    assert n == kept and (host(ind)[n:] == -1).all() and np.array_equal(host(ind)[:n], want[:n])
+    c8 = modules.box_3d_to_box_8co(dev(a[:4]))
+    from make_golden import box_3d_to_8co
+    np.testing.assert_allclose(host(c8), box_3d_to_8co(a[:4]), atol=1e-5)
