@@ -41,6 +41,10 @@ _SIGNATURES = {
     "hf_oriented_nms": [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp],
     "hf_pc_crop_and_sample": [_vp] * 6 + [_i] * 6 + [_vp] * 6 + [_vp],
     "hf_pc_crop_and_sample_grad_fts": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "hf_bn_workspace": [ctypes.c_longlong, _i],
+    "hf_bn_relu_fwd_train": [ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_bn_relu_fwd_eval": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "hf_bn_relu_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_version": [],
     "hf_strerror": [_i],
     "hf_last_hip_error": [],
@@ -48,6 +52,7 @@ _SIGNATURES = {
 _RESTYPES = {
     "hf_fps_workspace": _sz,
     "hf_oriented_nms_workspace": _sz,
+    "hf_bn_workspace": _sz,
     "hf_version": ctypes.c_char_p,
     "hf_strerror": ctypes.c_char_p,
 }

@@ -1,0 +1,365 @@
+// mlp.hip -- training-mode BatchNorm + ReLU on channel-last rows (R, C) for gfx950.
+//
+// Caller side of the hot path: the grouped-point MLP of a set-abstraction
+// level is tf_util.conv2d([1,1]) = matmul + bias, tf.contrib.layers.batch_norm(decay .9, eps 1e-3,
+// not fused) and ReLU (hf/core/feature_extractors/tf_util.py:180-203,554-581) applied to
+// R = B*M*K rows of 32..256 channels.  At R = 10^6 the three BN passes and the separate ReLU are
+// pure HBM traffic; the framework kernels they map to run at 0.8-1.4 TB/s on MI355X (profiles/).
+// Here:
+//   forward   stats pass (read x once; per-block fp32 partial sums, reduced in fp64 -> deterministic,
+//             no atomics) + one apply pass  y = relu(a*x + b)            (read x, write y)
+//   backward  reduce pass (read dy, x: sum dh, sum dh*xhat, the ReLU mask recomputed from x)
+//             + one dx pass                                              (read dy, x, write dx)
+// Thread geometry: a thread owns VEC consecutive channels for its whole life (scale/shift live in
+// registers) and strides over rows; 16-byte accesses when C % 4 == 0.
+#include <math.h>
+
+#include "hf_common.h"
+
+namespace hf {
+
+constexpr int kBnMaxBlocks = 2048;
+
+struct BnGeom {
+    int vec;       // floats per thread access (4 or 1)
+    int cv;        // vectors per row
+    int rpb;       // rows handled concurrently by one block
+    int threads;   // cv * rpb
+    int nblk;
+    long long rows_per_block;
+};
+
+static BnGeom bn_geom(long long rows, int c)
+{
+    BnGeom g;
+    g.vec = (c % 4 == 0) ? 4 : 1;
+    g.cv = c / g.vec;
+    g.rpb = g.cv >= 256 ? 1 : 256 / g.cv;
+    g.threads = g.cv * g.rpb;
+    long long nblk = (rows + g.rpb - 1) / g.rpb;
+    if (nblk > kBnMaxBlocks) nblk = kBnMaxBlocks;
+    if (nblk < 1) nblk = 1;
+    long long rpbk = (rows + nblk - 1) / nblk;
+    rpbk = (rpbk + g.rpb - 1) / g.rpb * g.rpb;
+    g.rows_per_block = rpbk;
+    g.nblk = static_cast<int>((rows + rpbk - 1) / rpbk);
+    return g;
+}
+
+template <int VEC> struct VecT { typedef float type __attribute__((ext_vector_type(VEC))); };
+template <> struct VecT<1> { typedef float type; };
+
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type ldv(const float *p) { return *reinterpret_cast<const typename VecT<VEC>::type *>(p); }
+template <int VEC>
+__device__ __forceinline__ void stv(float *p, typename VecT<VEC>::type v) { *reinterpret_cast<typename VecT<VEC>::type *>(p) = v; }
+template <int VEC> __device__ __forceinline__ float vget(const typename VecT<VEC>::type &v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float vget<1>(const float &v, int) { return v; }
+template <int VEC> __device__ __forceinline__ void vset(typename VecT<VEC>::type &v, int i, float f) { v[i] = f; }
+template <> __device__ __forceinline__ void vset<1>(float &v, int, float f) { v = f; }
+
+// block-level sum over the `rpb` row-lanes that share a channel vector; result valid where rsub == 0
+template <int VEC>
+__device__ __forceinline__ void reduce_rows(float (&a)[VEC], float (&b)[VEC], int cv, int rpb, int cvec, int rsub,
+                                            float *smem)
+{
+    // smem: rpb * cv * 2 * VEC floats
+    float *mine = smem + (static_cast<size_t>(rsub) * cv + cvec) * 2 * VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { mine[i] = a[i]; mine[VEC + i] = b[i]; }
+    __syncthreads();
+    if (rsub == 0) {
+        for (int r = 1; r < rpb; ++r) {
+            const float *o = smem + (static_cast<size_t>(r) * cv + cvec) * 2 * VEC;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { a[i] += o[i]; b[i] += o[VEC + i]; }
+        }
+    }
+}
+
+// partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over the block's rows
+template <int VEC>
+__global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
+                                const float *__restrict__ x, float *__restrict__ partial)
+{
+    extern __shared__ float smem[];
+    const int t = threadIdx.x;
+    const int cvec = t % cv, rsub = t / cv;
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    for (long long r = r0 + rsub; r < r1; r += rpb) {
+        const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const float f = vget<VEC>(v, i); s[i] += f; q[i] += f * f; }
+    }
+    reduce_rows<VEC>(s, q, cv, rpb, cvec, rsub, smem);
+    if (rsub == 0) {
+        // partial[which][channel][block]: the finalize kernel reads one channel's partials contiguously
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            partial[(static_cast<size_t>(cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = s[i];
+            partial[(static_cast<size_t>(c + cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = q[i];
+        }
+    }
+}
+
+// one 256-thread workgroup per channel: fp64 tree reduction of that channel's two partial rows
+__device__ __forceinline__ void bn_reduce_channel(const float *__restrict__ partial, int c, int nblk, int ch, double &s,
+                                                  double &q)
+{
+    __shared__ double red[2][256];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    const float *p0 = partial + static_cast<size_t>(ch) * kBnMaxBlocks;
+    const float *p1 = partial + static_cast<size_t>(c + ch) * kBnMaxBlocks;
+    for (int i = t; i < nblk; i += 256) { a += static_cast<double>(p0[i]); b += static_cast<double>(p1[i]); }
+    red[0][t] = a;
+    red[1][t] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
+        __syncthreads();
+    }
+    s = red[0][0];
+    q = red[1][0];
+}
+
+// batch statistics, running statistics (torch / TF-EMA semantics: running = (1-m)*running + m*batch,
+// unbiased variance for the running estimate)
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, int c, int nblk,
+                                                                const float *__restrict__ partial, float eps,
+                                                                float momentum, float *__restrict__ running_mean,
+                                                                float *__restrict__ running_var,
+                                                                float *__restrict__ save_mean,
+                                                                float *__restrict__ save_invstd)
+{
+    const int ch = blockIdx.x;
+    double s, q;
+    bn_reduce_channel(partial, c, nblk, ch, s, q);
+    if (threadIdx.x != 0) return;
+    const double mean = s / static_cast<double>(rows);
+    double var = q / static_cast<double>(rows) - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[ch] = static_cast<float>(mean);
+    save_invstd[ch] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    if (running_mean) running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * static_cast<float>(mean);
+    if (running_var) {
+        const double unbiased = rows > 1 ? var * static_cast<double>(rows) / static_cast<double>(rows - 1) : var;
+        running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * static_cast<float>(unbiased);
+    }
+}
+
+// y = relu?(gamma*invstd*(x-mean) + beta)
+template <int VEC>
+__global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
+                                const float *__restrict__ x, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, const float *__restrict__ mean,
+                                const float *__restrict__ invstd, int relu, float *__restrict__ y)
+{
+    const int t = threadIdx.x;
+    const int cvec = t % cv, rsub = t / cv;
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int ch = cvec * VEC + i;
+        a[i] = gamma[ch] * invstd[ch];
+        b[i] = beta[ch] - mean[ch] * a[i];
+    }
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long long r = r0 + rsub; r < r1; r += rpb) {
+        const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
+        typename VecT<VEC>::type o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float h = a[i] * vget<VEC>(v, i) + b[i];
+            if (relu) h = fmaxf(h, 0.0f);
+            vset<VEC>(o, i, h);
+        }
+        stv<VEC>(y + r * c + cvec * VEC, o);
+    }
+}
+
+// partial[blk][0][c] = sum dh, partial[blk][1][c] = sum dh*xhat  (dh = dy masked by the ReLU of a*x+b)
+template <int VEC>
+__global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
+                                     const float *__restrict__ x, const float *__restrict__ dy,
+                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                     const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                                     float *__restrict__ partial)
+{
+    extern __shared__ float smem[];
+    const int t = threadIdx.x;
+    const int cvec = t % cv, rsub = t / cv;
+    float a[VEC], b[VEC], mu[VEC], is[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int ch = cvec * VEC + i;
+        mu[i] = mean[ch]; is[i] = invstd[ch];
+        a[i] = gamma[ch] * is[i];
+        b[i] = beta[ch] - mu[i] * a[i];
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long long r = r0 + rsub; r < r1; r += rpb) {
+        const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
+        const typename VecT<VEC>::type g = ldv<VEC>(dy + r * c + cvec * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float xv = vget<VEC>(v, i);
+            float dh = vget<VEC>(g, i);
+            if (relu && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
+            s1[i] += dh;
+            s2[i] += dh * ((xv - mu[i]) * is[i]);
+        }
+    }
+    reduce_rows<VEC>(s1, s2, cv, rpb, cvec, rsub, smem);
+    if (rsub == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            partial[(static_cast<size_t>(cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = s1[i];
+            partial[(static_cast<size_t>(c + cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = s2[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int c, int nblk, const float *__restrict__ partial,
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int ch = blockIdx.x;
+    double s1, s2;
+    bn_reduce_channel(partial, c, nblk, ch, s1, s2);
+    if (threadIdx.x != 0) return;
+    dbeta[ch] = static_cast<float>(s1);
+    dgamma[ch] = static_cast<float>(s2);
+}
+
+// dx = gamma*invstd*(dh - dbeta/R - xhat*dgamma/R)
+template <int VEC>
+__global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
+                                 const float *__restrict__ x, const float *__restrict__ dy,
+                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                 const float *__restrict__ mean, const float *__restrict__ invstd,
+                                 const float *__restrict__ dgamma, const float *__restrict__ dbeta, int relu,
+                                 float *__restrict__ dx)
+{
+    const int t = threadIdx.x;
+    const int cvec = t % cv, rsub = t / cv;
+    const float inv_r = 1.0f / static_cast<float>(rows);
+    float a[VEC], b[VEC], mu[VEC], is[VEC], c1[VEC], c2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int ch = cvec * VEC + i;
+        mu[i] = mean[ch]; is[i] = invstd[ch];
+        a[i] = gamma[ch] * is[i];
+        b[i] = beta[ch] - mu[i] * a[i];
+        c1[i] = dbeta[ch] * inv_r;
+        c2[i] = dgamma[ch] * inv_r;
+    }
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long long r = r0 + rsub; r < r1; r += rpb) {
+        const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
+        const typename VecT<VEC>::type g = ldv<VEC>(dy + r * c + cvec * VEC);
+        typename VecT<VEC>::type o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float xv = vget<VEC>(v, i);
+            float dh = vget<VEC>(g, i);
+            if (relu && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
+            const float xhat = (xv - mu[i]) * is[i];
+            vset<VEC>(o, i, a[i] * (dh - c1[i] - xhat * c2[i]));
+        }
+        stv<VEC>(dx + r * c + cvec * VEC, o);
+    }
+}
+
+static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+}  // namespace hf
+
+using namespace hf;
+
+HF_API size_t hf_bn_workspace(long long rows, int c)
+{
+    if (rows <= 0 || c <= 0) return 0;
+    return sizeof(float) * 2 * static_cast<size_t>(c) * kBnMaxBlocks;
+}
+
+HF_API int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps,
+                                float momentum, float *running_mean, float *running_var, int relu, float *y,
+                                float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
+                                hf_stream_t stream)
+{
+    if (rows <= 0 || c <= 0 || c > 4096 || !x || !gamma || !beta || !y || !save_mean || !save_invstd) return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !(aligned16(x) && aligned16(y))) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, partial);
+    else
+        hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, partial);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps,
+                       momentum, running_mean, running_var, save_mean, save_invstd);
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y);
+    return launch_status();
+}
+
+HF_API int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const float *gamma, const float *beta,
+                               const float *mean, const float *invstd, int relu, float *y, hf_stream_t stream)
+{
+    if (rows <= 0 || c <= 0 || c > 4096 || !x || !gamma || !beta || !mean || !invstd || !y) return HF_EINVAL;
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !(aligned16(x) && aligned16(y))) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, gamma, beta, mean, invstd, relu, y);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, gamma, beta, mean, invstd, relu, y);
+    return launch_status();
+}
+
+HF_API int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
+                          const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
+                          float *dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows <= 0 || c <= 0 || c > 4096 || !x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma ||
+        !dbeta)
+        return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx))) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, partial, dgamma, dbeta);
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx);
+    else
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx);
+    return launch_status();
+}

@@ -1,0 +1,73 @@
+"""Fused training-mode BatchNorm(+ReLU) over channel-last rows -- the MLP half of a set-abstraction
+level (tf_util.conv2d's batch_norm + relu, hf/core/feature_extractors/tf_util.py:190-203,554-581).
+
+HIP kernels in csrc/mlp.hip behind hf_bn_relu_* (include/hfops.h); no framework fallback on the GPU
+path: CUDA tensors always take the HIP kernels."""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _workspace(rows, c, device):
+    nbytes = _lib.lib().hf_bn_workspace(rows, c)
+    return torch.empty((nbytes // 4,), dtype=torch.float32, device=device), nbytes
+
+
+class _BNReLUTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        rows, c = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
+        ws, nbytes = _workspace(rows, c, x.device)
+        check(_lib.lib().hf_bn_relu_fwd_train(rows, c, ptr(x), ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
+                                              ptr(running_var), 1 if relu else 0, ptr(y), ptr(mean), ptr(invstd),
+                                              ptr(ws), nbytes, stream_ptr()), "bn_relu_fwd_train")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        rows, c = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        ws, nbytes = _workspace(rows, c, x.device)
+        check(_lib.lib().hf_bn_relu_bwd(rows, c, ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
+                                        1 if ctx.relu else 0, ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes,
+                                        stream_ptr()), "bn_relu_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class BatchNormReLU(nn.Module):
+    """BatchNorm over the last dimension of (rows, C) followed by ReLU, one fused op.
+    Parameter / buffer names follow nn.BatchNorm1d (weight, bias, running_mean, running_var)."""
+
+    def __init__(self, num_features, eps=1e-3, momentum=0.1, relu=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.relu = num_features, eps, momentum, relu
+        self.weight = nn.Parameter(torch.ones(num_features))   # gamma: tf.constant_initializer(1.0)
+        self.bias = nn.Parameter(torch.zeros(num_features))    # beta: 0
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def forward(self, x):
+        assert x.dim() == 2 and x.shape[1] == self.num_features
+        if not x.is_cuda:
+            raise RuntimeError("BatchNormReLU: heterofusionrcnn_amd has no CPU implementation")
+        x = x.contiguous()
+        if self.training:
+            return _BNReLUTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                      self.momentum, self.relu)
+        y = torch.empty_like(x)
+        invstd = torch.rsqrt(self.running_var + self.eps)
+        check(_lib.lib().hf_bn_relu_fwd_eval(x.shape[0], x.shape[1], ptr(x), ptr(self.weight), ptr(self.bias),
+                                             ptr(self.running_mean), ptr(invstd), 1 if self.relu else 0, ptr(y),
+                                             stream_ptr()), "bn_relu_fwd_eval")
+        return y

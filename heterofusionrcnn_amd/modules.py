@@ -22,6 +22,7 @@ import torch.nn as nn
 from .grouping import group_point, knn_point, query_ball_group, query_ball_point
 from .interpolate import three_interpolate, three_nn
 from .sampling import farthest_point_sample, gather_point
+from .mlp import BatchNormReLU
 from .bev_iou import compute_bev_iou as _compute_bev_iou, oriented_nms as _oriented_nms
 
 
@@ -74,15 +75,16 @@ class SharedMLPLayer(nn.Module):
         self.fc = nn.Linear(cin, cout, bias=True)
         nn.init.xavier_uniform_(self.fc.weight)     # tf.contrib.layers.xavier_initializer (tf_util.py:42)
         nn.init.zeros_(self.fc.bias)                # tf.constant_initializer(0.0) (tf_util.py:188)
-        self.bn = nn.BatchNorm1d(cout, eps=1e-3, momentum=1.0 - bn_decay) if bn else None
+        # batch norm (moments over every axis but channels, tf_util.py:571) and ReLU as ONE fused HIP op
+        self.bn = BatchNormReLU(cout, eps=1e-3, momentum=1.0 - bn_decay, relu=relu) if bn else None
         self.relu = relu
 
     def forward(self, x):
         shape = x.shape
         y = tall_skinny_linear(x.reshape(-1, shape[-1]), self.fc.weight, self.fc.bias)
         if self.bn is not None:
-            y = self.bn(y)                          # moments over every axis but channels (tf_util.py:571)
-        if self.relu:
+            y = self.bn(y)
+        elif self.relu:
             y = torch.relu(y)
         return y.reshape(*shape[:-1], y.shape[-1])
 

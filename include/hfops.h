@@ -160,6 +160,28 @@ int hf_pc_crop_and_sample_grad_fts(const int *box_ind, const int *crop_ind, cons
                                    int num_boxes, int batch, int npts, int resize, int channel, float *grad_fts,
                                    hf_stream_t stream);
 
+/* ------------------------------------------------- callers of the path: the grouped-point MLP */
+
+/* Training-mode batch norm (+ optional ReLU) over channel-last rows x (rows, c): the
+ * tf_util.batch_norm_template + tf.nn.relu pair inside tf_util.conv2d
+ * (hf/core/feature_extractors/tf_util.py:190-203,554-581; decay = 1 - momentum, epsilon = eps).
+ * Batch statistics are reduced deterministically (per-block fp32 partials, fp64 final reduction).
+ * running_mean / running_var (may be NULL) are updated as (1-momentum)*running + momentum*batch
+ * (unbiased variance).  save_mean / save_invstd (c floats each) feed the backward pass.
+ * workspace: hf_bn_workspace(rows, c) bytes of device scratch. */
+size_t hf_bn_workspace(long long rows, int c);
+int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps,
+                         float momentum, float *running_mean, float *running_var, int relu, float *y,
+                         float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
+                         hf_stream_t stream);
+/* inference: y = relu?(gamma*invstd*(x-mean)+beta) with caller-provided mean / invstd */
+int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const float *gamma, const float *beta,
+                        const float *mean, const float *invstd, int relu, float *y, hf_stream_t stream);
+/* backward of hf_bn_relu_fwd_train: dx (rows,c), dgamma (c), dbeta (c); the ReLU mask is recomputed from x */
+int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
+                   const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
+                   float *dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

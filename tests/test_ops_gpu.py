@@ -670,3 +670,38 @@ def test_iou3d_and_nms_adapters(hf, oracle_mod):
     c8 = modules.box_3d_to_box_8co(dev(a[:4]))
     from make_golden import box_3d_to_8co
     np.testing.assert_allclose(host(c8), box_3d_to_8co(a[:4]), atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,c,relu", [(5000, 32, True), (777, 96, True), (4096, 196, False), (300, 7, True),
+                                         (70000, 64, True), (33, 256, True)])
+def test_fused_bn_relu_against_torch(hf, rows, c, relu):
+    """csrc/mlp.hip vs nn.BatchNorm1d(eps=1e-3, momentum=0.1) [+ relu]: forward, backward, running stats, eval"""
+    from heterofusionrcnn_amd.mlp import BatchNormReLU
+    torch.manual_seed(rows + c)
+    x = (torch.randn(rows, c, device="cuda") * 2.0 + 0.5)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.1).cuda()
+    mine = BatchNormReLU(c, eps=1e-3, momentum=0.1, relu=relu).cuda()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-0.5, 0.5)
+        mine.weight.copy_(ref.weight); mine.bias.copy_(ref.bias)
+    x1 = x.clone().requires_grad_(True)
+    x2 = x.clone().requires_grad_(True)
+    y1 = ref(x1)
+    if relu:
+        y1 = torch.relu(y1)
+    y2 = mine(x2)
+    torch.testing.assert_close(y2, y1, rtol=1e-4, atol=1e-5)
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g)
+    torch.testing.assert_close(x2.grad, x1.grad, rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(mine.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-3 * (rows ** 0.5) * 1e-1)
+    torch.testing.assert_close(mine.bias.grad, ref.bias.grad, rtol=1e-3, atol=1e-3 * (rows ** 0.5) * 1e-1)
+    torch.testing.assert_close(mine.running_mean, ref.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mine.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        e1 = ref(x)
+        if relu:
+            e1 = torch.relu(e1)
+        torch.testing.assert_close(mine(x), e1, rtol=1e-4, atol=1e-5)
