@@ -124,6 +124,18 @@ def headline_kernel_burst(hf, xyz, launches=200):
     return 1e3 * e0.elapsed_time(e1) / launches, launches
 
 
+def measured_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass on gfx950, so they are collected by scripts/roofline_kernel.py under
+    `rocprofv3 --pmc ...` and stored in profiles/roofline_traffic.json with their provenance)."""
+    path = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def per_op_table(hf, xyz):
     """device time of each op at the headline shapes (us per launch)"""
     t = {}
@@ -209,18 +221,12 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=16)
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from heterofusionrcnn_amd import dp
+    ctx = dp.init("nccl")   # RCCL; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher
+    world, rank, local_rank = ctx.world, ctx.rank, ctx.local_rank
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                          "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import heterofusionrcnn_amd as hf
     from heterofusionrcnn_amd import modules
@@ -231,11 +237,8 @@ def main():
 
     torch.manual_seed(1234)  # same initial weights on every rank (the reference broadcasts from rank 0)
     model = modules.PointnetSAFPStack(in_channel=1, sa=SA, fp=FP).cuda()
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=64,
-                                                        gradient_as_bucket_view=True)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3 * world)  # lr x world size: optimizer_builder.py:105
+    net = dp.wrap_model(model, ctx)                            # broadcast from rank 0 + gradient all-reduce (RCCL)
+    opt = torch.optim.Adam(net.parameters(), lr=dp.scaled_lr(1e-3, world))  # optimizer_builder.py:105
 
     rng = np.random.default_rng(1000 + rank)                   # rank-sharded synthetic frames
     xyz = torch.from_numpy(kitti_uniform(rng, B, N0)).cuda()
@@ -263,24 +266,14 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
+    dp.fence(ctx)
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    fence()
-    dt = time.perf_counter() - t0
+    dp.fence(ctx)
+    dt = dp.max_over_ranks(time.perf_counter() - t0, ctx)
     timer.enabled = False
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
     assert torch.isfinite(loss).item(), "loss is not finite"
 
     result = None
@@ -302,7 +295,7 @@ def main():
             "roofline": {"kernel": "query_ball_point+group_point fused (hf_query_ball_group_xyz), B=8 N=16384 M=4096 K=32",
                          "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                         "traffic": None, "algorithmic_bytes": algo, "avg_launch_us": round(k_us, 3) if k_us else None,
+                         "traffic": measured_traffic(), "algorithmic_bytes": algo, "avg_launch_us": round(k_us, 3) if k_us else None,
                          "launches_timed": n_burst,
                          "in_step_avg_launch_us": round(in_step_us, 3) if in_step_us else None,
                          "in_step_launches": len(timer.pairs)},
@@ -312,9 +305,7 @@ def main():
             result["extra"] = per_op_table(hf, xyz)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_frames)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dp.shutdown(ctx)
     if rank == 0:
         print(json.dumps(result), flush=True)
 

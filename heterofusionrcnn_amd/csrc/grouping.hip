@@ -181,7 +181,10 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
 
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int slab = blockIdx.x, bb = blockIdx.y;
+    // grid = (clouds, slabs): linear workgroup id = cloud + B*slab, and workgroups are dealt round-robin over
+    // the 8 XCDs, so with B = 8 all slabs of one cloud share ONE XCD's L2 (the cloud is fetched once per XCD
+    // instead of once per XCD per cloud).  Placement is a speed matter only.
+    const int slab = blockIdx.y, bb = blockIdx.x;
     const float *p1 = xyz1 + static_cast<size_t>(bb) * n * 3;
     const float *p2 = xyz2 + static_cast<size_t>(bb) * m * 3;
 
@@ -603,7 +606,7 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
     else if (nsample <= 128) { qcap = 128; ccap = 2048; }
     else { qcap = 0; ccap = 0; }
     const bool finite_r = radius < 3.0e18f;  // padded boxes stay finite
-    if (qcap == 0 || !finite_r || force_bruteforce() || b > 65535 || static_cast<long long>(m) * kNumCU > 0x7fffffffLL)
+    if (qcap == 0 || !finite_r || force_bruteforce() || static_cast<long long>(m) * kNumCU > 0x7fffffffLL)
         return launch_ball_query_bruteforce(b, n, m, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
     // one workgroup per CU across the batch, at least ~64 queries per slab
     int nslab = kNumCU / b;
@@ -612,7 +615,7 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
     nslab = env_int("HF_QBP_SLABS", nslab);      // diagnostics only
     const int stop = env_int("HF_QBP_STOP", 0);  // diagnostics only: early exit after phase N (outputs invalid)
     const size_t lds = slab_lds_bytes(nsample, qcap, ccap);
-    dim3 grid(nslab, b);
+    dim3 grid(b, nslab);
     if (grouped) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
