@@ -29,6 +29,7 @@ _SIGNATURES = {
     "hf_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "hf_knn_point": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_select_top_k": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -4,15 +4,19 @@
 // (bev_iou/bev_iou.cpp:60-116: cudaMalloc, blocking D2H of the mask, host greedy sweep, H2D).
 //
 // Structure (both the IoU matrix and the NMS mask kernel):
+//   phase 0  one workgroup per 64 x 64 tile of pairs; cos/sin, rotated corners, centre and radius are
+//            computed ONCE per box into LDS (the reference redoes them for every pair);
 //   phase 1  every pair gets a trig-free bounding-circle test.  Far pairs are exactly 0 in the
 //            reference too (no edge crossing, no corner inside: bev_iou_g.cu:150-176 leave
 //            cnt = 0 -> area 0), so they are written as zeros straight away;
-//   phase 2  the few surviving pairs are compacted into an LDS queue and the expensive polygon
-//            clip (16 edge tests, atan2 sort, shoelace) runs on dense lanes instead of on
-//            1-2 live lanes per wave.
+//   phase 2  the few surviving pairs are compacted into an LDS queue; on dense lanes they get a
+//            separating-axis test (again exact-zero safe) and only then the expensive polygon clip
+//            (16 edge tests, atan2 sort, shoelace).
 // The clip itself follows the reference operation by operation (fp32, no contraction); cos/sin
 // are evaluated once per box per pair-side (cos(-a) == cos(a), sin(-a) == -sin(a) exactly).
 #include <math.h>
+
+#include <algorithm>
 
 #include "hf_common.h"
 
@@ -72,25 +76,82 @@ __device__ __forceinline__ Pt rot_center(Pt c, float ac, float as, Pt p)
     return r;
 }
 
-// box_overlap, bev_iou_g.cu:102-206
-__device__ float box_overlap(const float *a, const float *b)
+// Everything about one box that does not depend on its partner: evaluated once per box per tile
+// (the reference recomputes cos/sin and the rotated corners for every pair, bev_iou_g.cu:130-140).
+struct BoxPre {
+    Pt cor[4];              // rotated corners, order of bev_iou_g.cu:118-128
+    float cs, sn;           // cos(angle), sin(angle)
+    float box[5];           // x1, y1, x2, y2, angle
+    float cx, cy, rad;      // centre and a bound on the circumradius (half perimeter), for the first filter
+};
+
+__device__ __forceinline__ void box_precompute(const float *b, BoxPre &o)
 {
-    const float a_x1 = a[0], a_y1 = a[1], a_x2 = a[2], a_y2 = a[3], a_angle = a[4];
-    const float b_x1 = b[0], b_y1 = b[1], b_x2 = b[2], b_y2 = b[3], b_angle = b[4];
-    const Pt ca = { (a_x1 + a_x2) / 2, (a_y1 + a_y2) / 2 };
-    const Pt cb = { (b_x1 + b_x2) / 2, (b_y1 + b_y2) / 2 };
-    const float acs = cosf(a_angle), asn = sinf(a_angle);
-    const float bcs = cosf(b_angle), bsn = sinf(b_angle);
+#pragma unroll
+    for (int d = 0; d < 5; ++d) o.box[d] = b[d];
+    const Pt c = { (b[0] + b[2]) / 2, (b[1] + b[3]) / 2 };
+    o.cs = cosf(b[4]);
+    o.sn = sinf(b[4]);
+    o.cor[0] = rot_center(c, o.cs, o.sn, Pt{ b[0], b[1] });
+    o.cor[1] = rot_center(c, o.cs, o.sn, Pt{ b[2], b[1] });
+    o.cor[2] = rot_center(c, o.cs, o.sn, Pt{ b[2], b[3] });
+    o.cor[3] = rot_center(c, o.cs, o.sn, Pt{ b[0], b[3] });
+    o.cx = c.x;
+    o.cy = c.y;
+    o.rad = (fabsf(b[2] - b[0]) + fabsf(b[3] - b[1])) * 0.5f;
+}
+
+// first filter, 6 LDS words per pair: centres further apart than the two radius bounds plus a slack that
+// dwarfs MARGIN = 1e-5 and fp32 rounding.  true => the reference computes exactly 0 (no edge crossing, no
+// corner inside: bev_iou_g.cu:150-176 leave cnt = 0).
+__device__ __forceinline__ bool circles_apart(const BoxPre &a, const BoxPre &b)
+{
+    const float mag = fabsf(a.cx) + fabsf(a.cy) + fabsf(b.cx) + fabsf(b.cy) + a.rad + b.rad;
+    const float reach = a.rad + b.rad + 1e-3f + 1e-5f * mag;
+    const float dx = a.cx - b.cx, dy = a.cy - b.cy;
+    return dx * dx + dy * dy > reach * reach;  // NaN/inf compare false -> next filter
+}
+
+// second filter (survivors of the first only): separating-axis test over the four edge directions of the
+// rotated corners, accepted only when the gap along some axis exceeds the same kind of slack.
+__device__ __forceinline__ bool surely_disjoint(const BoxPre &a, const BoxPre &b)
+{
+    float mag = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        mag = fmaxf(mag, fmaxf(fmaxf(fabsf(a.cor[k].x), fabsf(a.cor[k].y)), fmaxf(fabsf(b.cor[k].x), fabsf(b.cor[k].y))));
+    const float slack = 1e-3f + 1e-5f * mag;
+    bool sep = false;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const BoxPre &p = which == 0 ? a : b;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            // axis = edge direction cor[e+1] - cor[e] (not normalised; gaps are compared scaled by its length)
+            const float ux = p.cor[e + 1].x - p.cor[e].x, uy = p.cor[e + 1].y - p.cor[e].y;
+            const float len = fabsf(ux) + fabsf(uy);  // >= |u|: makes the required gap larger, never smaller
+            float amin = INFINITY, amax = -INFINITY, bmin = INFINITY, bmax = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float pa = a.cor[k].x * ux + a.cor[k].y * uy;
+                const float pb = b.cor[k].x * ux + b.cor[k].y * uy;
+                amin = fminf(amin, pa); amax = fmaxf(amax, pa);
+                bmin = fminf(bmin, pb); bmax = fmaxf(bmax, pb);
+            }
+            const float gap = fmaxf(bmin - amax, amin - bmax);
+            if (gap > (slack + 4e-6f * mag) * len && len > 0.f) sep = true;  // projections round at ~mag*|u|*1e-6
+        }
+    }
+    return sep;  // NaN / inf inputs compare false -> full path
+}
+
+// box_overlap, bev_iou_g.cu:102-206, on precomputed corners
+__device__ float box_overlap(const BoxPre &pa, const BoxPre &pb)
+{
     Pt A[5], B[5];
-    A[0] = rot_center(ca, acs, asn, Pt{ a_x1, a_y1 });
-    A[1] = rot_center(ca, acs, asn, Pt{ a_x2, a_y1 });
-    A[2] = rot_center(ca, acs, asn, Pt{ a_x2, a_y2 });
-    A[3] = rot_center(ca, acs, asn, Pt{ a_x1, a_y2 });
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { A[k] = pa.cor[k]; B[k] = pb.cor[k]; }
     A[4] = A[0];
-    B[0] = rot_center(cb, bcs, bsn, Pt{ b_x1, b_y1 });
-    B[1] = rot_center(cb, bcs, bsn, Pt{ b_x2, b_y1 });
-    B[2] = rot_center(cb, bcs, bsn, Pt{ b_x2, b_y2 });
-    B[3] = rot_center(cb, bcs, bsn, Pt{ b_x1, b_y2 });
     B[4] = B[0];
 
     Pt cp[24];
@@ -109,11 +170,11 @@ __device__ float box_overlap(const float *a, const float *b)
         }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (in_box2d(a, acs, -asn, B[k])) {
+        if (in_box2d(pa.box, pa.cs, -pa.sn, B[k])) {
             ctr.x = ctr.x + B[k].x; ctr.y = ctr.y + B[k].y;
             cp[cnt++] = B[k];
         }
-        if (in_box2d(b, bcs, -bsn, A[k])) {
+        if (in_box2d(pb.box, pb.cs, -pb.sn, A[k])) {
             ctr.x = ctr.x + A[k].x; ctr.y = ctr.y + A[k].y;
             cp[cnt++] = A[k];
         }
@@ -147,69 +208,76 @@ __device__ __forceinline__ float iou_from_overlap(const float *a, const float *b
     return s / fmaxf(sa + sb - s, kIouEps);
 }
 
-// Conservative "cannot touch" test, no trig: centres further apart than the sum of the boxes'
-// half-perimeter bounds (>= circumradius) plus a slack that dwarfs MARGIN=1e-5 and fp32 rounding
-// at these magnitudes.  true => the reference computes exactly 0 overlap / 0 IoU.
-__device__ __forceinline__ bool surely_disjoint(const float *a, const float *b)
+// ---------------------------------------------------------------- 64 x 64 pair tiles
+constexpr int kTileThreads = 256;
+
+struct TileShared {
+    BoxPre ra[64], cb[64];
+    int queue[64 * 64];
+    unsigned long long words[64];
+    int qcount;
+};
+
+__device__ __forceinline__ void tile_stage(TileShared &sh, const float *boxes_r, int row0, int row_size,
+                                           const float *boxes_c, int col0, int col_size)
 {
-    const float cax = (a[0] + a[2]) * 0.5f, cay = (a[1] + a[3]) * 0.5f;
-    const float cbx = (b[0] + b[2]) * 0.5f, cby = (b[1] + b[3]) * 0.5f;
-    const float ra = (fabsf(a[2] - a[0]) + fabsf(a[3] - a[1])) * 0.5f;
-    const float rb = (fabsf(b[2] - b[0]) + fabsf(b[3] - b[1])) * 0.5f;
-    const float mag = fabsf(cax) + fabsf(cay) + fabsf(cbx) + fabsf(cby) + ra + rb;
-    const float reach = ra + rb + 1e-3f + 1e-5f * mag;
-    const float dx = cax - cbx, dy = cay - cby;
-    return dx * dx + dy * dy > reach * reach;  // NaN/inf inputs compare false -> full path
+    const int t = threadIdx.x;
+    if (t < 64) {
+        if (t < row_size) box_precompute(boxes_r + static_cast<size_t>(row0 + t) * 5, sh.ra[t]);
+        sh.words[t] = 0ull;
+    } else if (t < 128) {
+        const int c = t - 64;
+        if (c < col_size) box_precompute(boxes_c + static_cast<size_t>(col0 + c) * 5, sh.cb[c]);
+    }
+    if (t == 128) sh.qcount = 0;
 }
 
-// ---------------------------------------------------------------- IoU matrix
-constexpr int kIouThreads = 256;
-constexpr int kIouPerThread = 8;
-constexpr int kIouChunk = kIouThreads * kIouPerThread;  // pairs per block
-
-__global__ __launch_bounds__(kIouThreads) void bev_iou_kernel(int num_a, const float *__restrict__ boxes_a, int num_b,
-                                                              const float *__restrict__ boxes_b,
-                                                              float *__restrict__ ans_overlap,
-                                                              float *__restrict__ ans_iou)
+// IoU matrix: one workgroup per 64 x 64 tile of (a, b) pairs
+__global__ __launch_bounds__(kTileThreads) void bev_iou_kernel(int num_a, const float *__restrict__ boxes_a, int num_b,
+                                                               const float *__restrict__ boxes_b,
+                                                               float *__restrict__ ans_overlap,
+                                                               float *__restrict__ ans_iou)
 {
-    __shared__ int queue[kIouChunk];
-    __shared__ int qcount;
-    const long long total = static_cast<long long>(num_a) * num_b;
-    const long long base = static_cast<long long>(blockIdx.x) * kIouChunk;
-    if (threadIdx.x == 0) qcount = 0;
+    __shared__ TileShared sh;
+    const int t = threadIdx.x;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    const int row_size = min(num_a - row0, 64), col_size = min(num_b - col0, 64);
+    tile_stage(sh, boxes_a, row0, row_size, boxes_b, col0, col_size);
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < kIouPerThread; ++it) {
-        const int local = it * kIouThreads + threadIdx.x;
-        const long long e = base + local;
-        if (e < total) {
-            const int ia = static_cast<int>(e / num_b), ib = static_cast<int>(e - static_cast<long long>(ia) * num_b);
-            if (surely_disjoint(boxes_a + static_cast<size_t>(ia) * 5, boxes_b + static_cast<size_t>(ib) * 5)) {
-                if (ans_overlap) ans_overlap[e] = 0.0f;
-                if (ans_iou) ans_iou[e] = 0.0f;
+    // filter 1 (all pairs, cheap): bounding circles
+    for (int e = t; e < 64 * 64; e += kTileThreads) {
+        const int r = e >> 6, c = e & 63;
+        if (r < row_size && c < col_size) {
+            if (circles_apart(sh.ra[r], sh.cb[c])) {
+                const size_t o = static_cast<size_t>(row0 + r) * num_b + col0 + c;
+                if (ans_overlap) ans_overlap[o] = 0.0f;
+                if (ans_iou) ans_iou[o] = 0.0f;
             } else {
-                queue[atomicAdd(&qcount, 1)] = local;
+                sh.queue[atomicAdd(&sh.qcount, 1)] = e;
             }
         }
     }
     __syncthreads();
-    const int nq = qcount;
-    for (int q = threadIdx.x; q < nq; q += kIouThreads) {
-        const long long e = base + queue[q];
-        const int ia = static_cast<int>(e / num_b), ib = static_cast<int>(e - static_cast<long long>(ia) * num_b);
-        float a[5], b[5];
-#pragma unroll
-        for (int d = 0; d < 5; ++d) { a[d] = boxes_a[static_cast<size_t>(ia) * 5 + d]; b[d] = boxes_b[static_cast<size_t>(ib) * 5 + d]; }
-        const float s = box_overlap(a, b);
-        if (ans_overlap) ans_overlap[e] = s;
-        if (ans_iou) ans_iou[e] = iou_from_overlap(a, b, s);
+    // filter 2 (survivors only, dense lanes): separating axes; then the clip on what is left
+    const int nq = sh.qcount;
+    for (int q = t; q < nq; q += kTileThreads) {
+        const int e = sh.queue[q];
+        const int r = e >> 6, c = e & 63;
+        float s = 0.0f, iou = 0.0f;
+        if (!surely_disjoint(sh.ra[r], sh.cb[c])) {
+            s = box_overlap(sh.ra[r], sh.cb[c]);
+            iou = iou_from_overlap(sh.ra[r].box, sh.cb[c].box, s);
+        }
+        const size_t o = static_cast<size_t>(row0 + r) * num_b + col0 + c;
+        if (ans_overlap) ans_overlap[o] = s;
+        if (ans_iou) ans_iou[o] = iou;
     }
 }
 
 // ---------------------------------------------------------------- NMS mask
 // one block per (row tile, col tile) of 64x64 pairs; mask word (row, col tile) bit j set iff
 // iou(row, col*64+j) > thresh, j > row inside the diagonal tile (bev_iou_g.cu:256-298).
-constexpr int kNmsThreads = 256;
+constexpr int kNmsThreads = kTileThreads;
 
 template <bool UPPER_ONLY>
 __global__ __launch_bounds__(kNmsThreads) void nms_mask_kernel(int n, float thresh, const float *__restrict__ boxes,
@@ -217,58 +285,75 @@ __global__ __launch_bounds__(kNmsThreads) void nms_mask_kernel(int n, float thre
 {
     const int row_t = blockIdx.y, col_t = blockIdx.x;
     if (UPPER_ONLY && col_t < row_t) return;  // never read by the sweep (bev_iou.cpp:100-103 starts at nblock)
-    __shared__ float rb[64 * 5], cbx[64 * 5];
-    __shared__ unsigned long long words[64];
-    __shared__ int queue[64 * 64];
-    __shared__ int qcount;
+    __shared__ TileShared sh;
     const int t = threadIdx.x;
     const int row_size = min(n - row_t * 64, 64), col_size = min(n - col_t * 64, 64);
-    for (int e = t; e < row_size * 5; e += kNmsThreads) rb[e] = boxes[static_cast<size_t>(row_t) * 64 * 5 + e];
-    for (int e = t; e < col_size * 5; e += kNmsThreads) cbx[e] = boxes[static_cast<size_t>(col_t) * 64 * 5 + e];
-    if (t < 64) words[t] = 0ull;
-    if (t == 0) qcount = 0;
+    tile_stage(sh, boxes, row_t * 64, row_size, boxes, col_t * 64, col_size);
     __syncthreads();
     for (int e = t; e < 64 * 64; e += kNmsThreads) {
         const int r = e >> 6, c = e & 63;
         const bool valid = r < row_size && c < col_size && !(row_t == col_t && c <= r);
-        if (valid && !surely_disjoint(rb + r * 5, cbx + c * 5)) queue[atomicAdd(&qcount, 1)] = e;
+        if (valid && !circles_apart(sh.ra[r], sh.cb[c])) sh.queue[atomicAdd(&sh.qcount, 1)] = e;
     }
     __syncthreads();
-    const int nq = qcount;
+    const int nq = sh.qcount;
     for (int q = t; q < nq; q += kNmsThreads) {
-        const int e = queue[q];
+        const int e = sh.queue[q];
         const int r = e >> 6, c = e & 63;
-        const float s = box_overlap(rb + r * 5, cbx + c * 5);
-        if (iou_from_overlap(rb + r * 5, cbx + c * 5, s) > thresh) atomicOr(&words[r], 1ull << c);
+        if (surely_disjoint(sh.ra[r], sh.cb[c])) continue;
+        const float s = box_overlap(sh.ra[r], sh.cb[c]);
+        if (iou_from_overlap(sh.ra[r].box, sh.cb[c].box, s) > thresh) atomicOr(&sh.words[r], 1ull << c);
     }
     __syncthreads();
     const int col_blocks = (n + 63) / 64;
-    if (t < row_size) mask[(static_cast<size_t>(row_t) * 64 + t) * col_blocks + col_t] = words[t];
+    if (t < row_size) mask[(static_cast<size_t>(row_t) * 64 + t) * col_blocks + col_t] = sh.words[t];
 }
 
 // ---------------------------------------------------------------- greedy sweep on the device
-// bev_iou.cpp:87-112.  One 256-thread block: wave 0 resolves the 64 boxes of a column block
-// sequentially (their mutual suppression sits in the diagonal mask words, held one per lane),
-// then all waves OR the kept rows into the running removal words of the later column blocks.
-constexpr int kSweepThreads = 256;
+// bev_iou.cpp:87-112 without the host.  One 1024-thread workgroup walks the column blocks in order.
+// For column block `blk` the removal word is PULLED: remv = OR over every box kept so far of
+// mask[box][blk] (the kept list is in LDS; all threads OR their share, then a tree reduction) -- the
+// host loop pushes each kept row into all later words instead, which serialises on one thread.  Wave 0
+// then resolves the 64 boxes of the block against each other from the diagonal words (one per lane).
+constexpr int kSweepThreads = 1024;
 
 __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, const unsigned long long *__restrict__ mask,
                                                                   int *__restrict__ keep, int *__restrict__ num_kept)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long *remv = reinterpret_cast<unsigned long long *>(smem_raw);  // col_blocks words
-    __shared__ unsigned long long kept_bits;
+    int *kept_list = reinterpret_cast<int *>(smem_raw);  // up to n kept box indices
+    __shared__ unsigned long long red[kSweepThreads / 64];
+    __shared__ unsigned long long remv_word;
     __shared__ int kept_total;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cb = (n + 63) / 64;
-    for (int w = t; w < cb; w += kSweepThreads) remv[w] = 0ull;
     if (t == 0) kept_total = 0;
     __syncthreads();
     for (int blk = 0; blk < cb; ++blk) {
+        // ---- pull: which boxes of this block are already suppressed by earlier kept boxes ----
+        const int kt = kept_total;
+        unsigned long long acc = 0ull;
+        for (int i = t; i < kt; i += kSweepThreads) acc |= mask[static_cast<size_t>(kept_list[i]) * cb + blk];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned lo = __shfl_xor(static_cast<unsigned>(acc), d);
+            const unsigned hi = __shfl_xor(static_cast<unsigned>(acc >> 32), d);
+            acc |= (static_cast<unsigned long long>(hi) << 32) | lo;
+        }
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long r = 0ull;
+#pragma unroll
+            for (int w = 0; w < kSweepThreads / 64; ++w) r |= red[w];
+            remv_word = r;
+        }
+        __syncthreads();
+        // ---- wave 0: sequential resolution inside the block ----
         if (t < 64) {
             const int i = blk * 64 + t;
             const unsigned long long diag = i < n ? mask[static_cast<size_t>(i) * cb + blk] : 0ull;
-            unsigned long long word = remv[blk];
+            unsigned long long word = remv_word;
             const int lim = min(64, n - blk * 64);
             unsigned long long kb = 0ull;
             for (int l = 0; l < lim; ++l) {  // wave-uniform scalar loop
@@ -280,20 +365,12 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, const u
                 }
             }
             const int before = kept_total;
-            if ((kb >> t) & 1ull) keep[before + __builtin_popcountll(kb & ((1ull << t) - 1ull))] = i;
-            if (t == 0) { kept_bits = kb; kept_total = before + __builtin_popcountll(kb); }
-        }
-        __syncthreads();
-        const unsigned long long kb = kept_bits;
-        for (int w = blk + 1 + t; w < cb; w += kSweepThreads) {
-            unsigned long long acc = remv[w];
-            unsigned long long bits = kb;
-            while (bits) {
-                const int l = __builtin_ctzll(bits);
-                bits &= bits - 1ull;
-                acc |= mask[(static_cast<size_t>(blk) * 64 + l) * cb + w];
+            if ((kb >> t) & 1ull) {
+                const int pos = before + __builtin_popcountll(kb & ((1ull << t) - 1ull));
+                kept_list[pos] = i;
+                keep[pos] = i;
             }
-            remv[w] = acc;
+            if (t == 0) kept_total = before + __builtin_popcountll(kb);
         }
         __syncthreads();
     }
@@ -313,11 +390,21 @@ HF_API int hf_compute_bev_iou(int num_a, const float *boxes_a, int num_b, const 
     // ComputeBevIOUOp: N > 0, M > 0, (N,5) / (M,5)  (bev_iou.cpp:156-157)
     if (num_a <= 0 || num_b <= 0 || !boxes_a || !boxes_b) return HF_EINVAL;
     if (!ans_overlap && !ans_iou) return HF_OK;
-    const long long total = static_cast<long long>(num_a) * num_b;
-    const long long blocks = (total + kIouChunk - 1) / kIouChunk;
-    if (blocks > 0x7fffffffLL) return HF_EINVAL;
-    hipLaunchKernelGGL(bev_iou_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kIouThreads), 0, as_stream(stream),
-                       num_a, boxes_a, num_b, boxes_b, ans_overlap, ans_iou);
+    const int gy = (num_a + 63) / 64, gx = (num_b + 63) / 64;
+    if (gy > 65535) {
+        // very tall matrices: walk the rows in slabs of 65535 tiles
+        for (int y0 = 0; y0 < gy; y0 += 65535) {
+            const int rows0 = y0 * 64;
+            const int na = std::min(num_a - rows0, 65535 * 64);
+            hipLaunchKernelGGL(bev_iou_kernel, dim3(gx, (na + 63) / 64), dim3(kTileThreads), 0, as_stream(stream), na,
+                               boxes_a + static_cast<size_t>(rows0) * 5, num_b, boxes_b,
+                               ans_overlap ? ans_overlap + static_cast<size_t>(rows0) * num_b : nullptr,
+                               ans_iou ? ans_iou + static_cast<size_t>(rows0) * num_b : nullptr);
+        }
+        return launch_status();
+    }
+    hipLaunchKernelGGL(bev_iou_kernel, dim3(gx, gy), dim3(kTileThreads), 0, as_stream(stream), num_a, boxes_a, num_b,
+                       boxes_b, ans_overlap, ans_iou);
     return launch_status();
 }
 
@@ -346,8 +433,8 @@ HF_API int hf_oriented_nms(const float *boxes, int n, float thresh, int *keep, i
     if (n <= 0 || !(thresh >= 0.0f) || !boxes || !keep) return HF_EINVAL;
     if (!workspace || workspace_bytes < hf_oriented_nms_workspace(n)) return HF_EWORKSPACE;
     const int cb = (n + 63) / 64;
-    const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(cb);
-    if (cb > 65535 || lds > 150 * 1024) return HF_EINVAL;
+    const size_t lds = sizeof(int) * static_cast<size_t>(n);  // kept list
+    if (cb > 65535 || lds > 140 * 1024) return HF_EINVAL;     // n <= ~35 000 boxes (pre_nms_size is 9000)
     hipStream_t st = as_stream(stream);
     unsigned long long *mask = static_cast<unsigned long long *>(workspace);
     hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(cb, cb), dim3(kNmsThreads), 0, st, n, thresh, boxes, mask);

@@ -521,6 +521,65 @@ __global__ void group_point_grad_kernel(int n, int c, long long rows_per_batch, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// knn_point: the k nearest data points of every query, ascending (distance, index).
+// Caller side of the path: the reference builds a dense (b,m,n) distance
+// matrix |q|^2 - 2 q.p + |p|^2 with a batched matmul and takes tf.nn.top_k of its negation
+// (grouping/tf_grouping.py:62-95; hf/core/pointfly.py:185-212 does the same for PointCNN: 1 GiB per
+// frame at n = m = 16384).  Here: one thread per query, data streamed through LDS tiles, the k best
+// kept in a sorted per-thread LDS column; a candidate costs one compare unless it enters the list.
+// Distances are the direct (qx-px)^2+(qy-py)^2+(qz-pz)^2 (more accurate than the expanded form);
+// ties go to the lower index, tf.nn.top_k's documented rule.
+// ------------------------------------------------------------------------------------------
+constexpr int kKnnThreads = 256;
+constexpr int kKnnTile = 1024;
+
+__global__ __launch_bounds__(kKnnThreads) void knn_kernel(int n, int m, int k, const float *__restrict__ xyz1,
+                                                          const float *__restrict__ xyz2, float *__restrict__ val,
+                                                          int *__restrict__ idx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *tile = reinterpret_cast<float *>(smem_raw);        // kKnnTile*3
+    float *bd = tile + kKnnTile * 3;                          // k * kKnnThreads, column per thread
+    int *bi = reinterpret_cast<int *>(bd + static_cast<size_t>(k) * kKnnThreads);
+    const int t = threadIdx.x, bb = blockIdx.y;
+    const int j = blockIdx.x * kKnnThreads + t;
+    const float *p1 = xyz1 + static_cast<size_t>(bb) * n * 3;
+    const float *p2 = xyz2 + static_cast<size_t>(bb) * m * 3;
+    const bool live = j < m;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (live) { qx = p2[j * 3]; qy = p2[j * 3 + 1]; qz = p2[j * 3 + 2]; }
+    for (int s = 0; s < k; ++s) { bd[s * kKnnThreads + t] = INFINITY; bi[s * kKnnThreads + t] = 0; }
+    float worst = INFINITY;  // bd[k-1]
+    for (int base = 0; base < n; base += kKnnTile) {
+        const int tn = min(kKnnTile, n - base);
+        __syncthreads();
+        for (int e = t; e < tn * 3; e += kKnnThreads) tile[e] = p1[static_cast<size_t>(base) * 3 + e];
+        __syncthreads();
+        if (!live) continue;
+        for (int c = 0; c < tn; ++c) {
+            const float dx = qx - tile[c * 3], dy = qy - tile[c * 3 + 1], dz = qz - tile[c * 3 + 2];
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < worst) {  // strict: an equal distance with a higher index never displaces
+                int pos = k - 1;
+                while (pos > 0 && bd[(pos - 1) * kKnnThreads + t] > d) {
+                    bd[pos * kKnnThreads + t] = bd[(pos - 1) * kKnnThreads + t];
+                    bi[pos * kKnnThreads + t] = bi[(pos - 1) * kKnnThreads + t];
+                    --pos;
+                }
+                bd[pos * kKnnThreads + t] = d;
+                bi[pos * kKnnThreads + t] = base + c;
+                worst = bd[(k - 1) * kKnnThreads + t];
+            }
+        }
+    }
+    if (live) {
+        float *ov = val + (static_cast<size_t>(bb) * m + j) * k;
+        int *oi = idx + (static_cast<size_t>(bb) * m + j) * k;
+        for (int s = 0; s < k; ++s) { ov[s] = bd[s * kKnnThreads + t]; oi[s] = bi[s * kKnnThreads + t]; }
+    }
+}
+
 // select_top_k (SelectionSort op, tf_grouping_g.cu:83-123): one thread per (b,m) row, as the
 // reference; unused by every shipped config (kept for surface completeness).
 __global__ void select_top_k_kernel(int n, long long nrows, int k, const float *__restrict__ dist,
@@ -686,6 +745,21 @@ HF_API int hf_group_point_grad(int b, int n, int c, int m, int nsample, const fl
     const int block = 256;
     hipLaunchKernelGGL(group_point_grad_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c,
                        static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);
+    return launch_status();
+}
+
+HF_API int hf_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                        hf_stream_t stream)
+{
+    if (k <= 0 || b < 0 || n <= 0 || m < 0 || k > n || !xyz1 || !xyz2 || !val || !idx) return HF_EINVAL;
+    if (b == 0 || m == 0) return HF_OK;
+    const size_t lds = sizeof(float) * kKnnTile * 3 + (sizeof(float) + sizeof(int)) * static_cast<size_t>(k) * kKnnThreads;
+    if (lds > 150 * 1024 || b > 65535) return HF_EINVAL;  // k <= 67 (the reference uses 8..32)
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+    hipLaunchKernelGGL(knn_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, as_stream(stream), n, m, k,
+                       xyz1, xyz2, val, idx);
     return launch_status();
 }
 

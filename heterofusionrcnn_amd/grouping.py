@@ -99,15 +99,27 @@ def select_top_k(k, dist):
 
 
 def knn_point(k, xyz1, xyz2):
-    """xyz1 (B,N,C) data, xyz2 (B,M,C) queries -> (val (B,M,k) squared L2, idx (B,M,k) int32).
-    Reference: tf_grouping.py:62-95 builds |q|^2 - 2 q.p^T + |p|^2 with a batched matmul and
-    takes tf.nn.top_k of the negation; restated with the same three terms in torch (plumbing:
-    the dedicated kNN kernel is SURVEY.md 8f rank 1, not built yet)."""
+    """xyz1 (B,N,C) data, xyz2 (B,M,C) queries -> (val (B,M,k) squared L2 ascending, idx (B,M,k) int32).
+    Reference: tf_grouping.py:62-95 (dense |q|^2 - 2 q.p^T + |p|^2 matrix + tf.nn.top_k).  For C == 3 this is
+    the HIP kNN kernel (no (B,M,N) matrix; ties: lower index first).  Other channel counts keep the reference's
+    three-term formula in torch."""
+    k = int(k)
+    require(k > 0, "knn_point expects positive k")
     require(xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[0] == xyz2.shape[0] and
             xyz1.shape[2] == xyz2.shape[2], "knn_point expects (b,n,c) xyz1 and (b,m,c) xyz2")
+    require(k <= xyz1.shape[1], "knn_point expects k <= ndataset")
+    if xyz1.shape[2] == 3 and k <= 67:
+        xyz1 = dev_tensor(xyz1.detach(), torch.float32, "xyz1")
+        xyz2 = dev_tensor(xyz2.detach(), torch.float32, "xyz2")
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        val = torch.empty((b, m, k), dtype=torch.float32, device=xyz1.device)
+        idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
+        check(_lib.lib().hf_knn_point(b, n, m, k, ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), stream_ptr()), "knn_point")
+        return val, idx
     r1 = (xyz1 * xyz1).sum(dim=2, keepdim=True)              # (b,n,1)
     r2 = (xyz2 * xyz2).sum(dim=2, keepdim=True)              # (b,m,1)
     mul = torch.matmul(xyz2, xyz1.transpose(1, 2))           # (b,m,n)
     dist = r2 - 2 * mul + r1.transpose(1, 2)
-    val, idx = torch.topk(-dist, k=int(k), dim=2)
+    val, idx = torch.topk(-dist, k=k, dim=2)
     return -val, idx.to(torch.int32)

@@ -162,6 +162,13 @@ int hf_pc_crop_and_sample_grad_fts(const int *box_ind, const int *crop_ind, cons
 
 /* ------------------------------------------------- callers of the path: the grouped-point MLP */
 
+/* k nearest data points of every query: the knn_point of grouping/tf_grouping.py:62-95 (and PointCNN's
+ * knn_indices_general, hf/core/pointfly.py:185-212) without the dense (b,m,n) distance matrix.
+ * xyz1 (b,n,3) data, xyz2 (b,m,3) queries -> val (b,m,k) squared distances ascending, idx (b,m,k) int32;
+ * equal distances: lower index first (tf.nn.top_k's rule).  1 <= k <= min(n, 67). */
+int hf_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                 hf_stream_t stream);
+
 /* Training-mode batch norm (+ optional ReLU) over channel-last rows x (rows, c): the
  * tf_util.batch_norm_template + tf.nn.relu pair inside tf_util.conv2d
  * (hf/core/feature_extractors/tf_util.py:190-203,554-581; decay = 1 - momentum, epsilon = eps).

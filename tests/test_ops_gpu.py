@@ -705,3 +705,33 @@ def test_fused_bn_relu_against_torch(hf, rows, c, relu):
         if relu:
             e1 = torch.relu(e1)
         torch.testing.assert_close(mine(x), e1, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m,k", [(2, 2048, 512, 8), (1, 300, 1000, 32), (3, 64, 5, 64), (1, 5000, 257, 1)])
+def test_oracle_knn(hf, oracle_mod, b, n, m, k):
+    """hf_knn_point vs the oracle's k smallest (distance, index) pairs; duplicated data points exercise the
+    lower-index-first tie rule.  (The reference's tf.nn.top_k is third-party: parity unpinned beyond this rule.)"""
+    rng = np.random.default_rng(k * 31 + n)
+    x1 = kitti_uniform(rng, b, n)
+    x2 = kitti_uniform(rng, b, m)
+    if n >= 64:
+        x1[:, n // 2:n // 2 + 8] = x1[:, :8]
+        x2[:, :4] = x1[:, :4]
+    val, idx = hf.knn_point(k, dev(x1), dev(x2))
+    ov, oi = oracle_mod.knn_point(k, x1, x2)
+    assert np.array_equal(host(idx), oi)
+    assert np.array_equal(host(val), ov)
+    assert (np.diff(host(val), axis=-1) >= 0).all()
+
+
+def test_sample_and_group_knn_mode(hf, oracle_mod):
+    """sample_and_group(knn=True), the mode both shipped PointNet++ configs use (rpn_cars_pointnet.config:61)"""
+    from heterofusionrcnn_amd import modules
+    rng = np.random.default_rng(4)
+    xyz = kitti_uniform(rng, 2, 1024)
+    new_xyz, new_points, idx, gxyz = modules.sample_and_group(128, 0.0, 8, dev(xyz), None, knn=True)
+    o_new = oracle_mod.gather_point(xyz, oracle_mod.farthest_point_sample(128, xyz))
+    _, o_idx = oracle_mod.knn_point(8, xyz, o_new)
+    assert np.array_equal(host(idx), o_idx)
+    assert np.array_equal(host(gxyz), oracle_mod.group_point(xyz, o_idx) - o_new[:, :, None, :])
+    assert (host(idx)[:, :, 0] == oracle_mod.farthest_point_sample(128, xyz)).all()  # nearest neighbour = itself
