@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-table", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the geometry ops inline instead of one step ahead")
-    ap.add_argument("--cpu-frames", type=int, default=16)
+    ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
 
     from heterofusionrcnn_amd import dp
