@@ -164,6 +164,25 @@ def per_op_table(hf, xyz):
     t["bev_iou_Gboxpairs_per_s"] = 70000 * 64 / t["bev_iou_70000x64_us"] / 1e3
     nb = torch.from_numpy(rand_bev(rng, 9000)).cuda()
     t["oriented_nms_9000_us"] = time_op(lambda: hf.oriented_nms(nb, 0.8), iters=5, warm=1)
+    # kNN (PointCNN / knn-mode SA): K=8 neighbours of 4096 queries in 16384 points, no (B,M,N) matrix
+    t["knn_k8_16384x4096_us"] = time_op(lambda: hf.knn_point(8, xyz, new_xyz), iters=10, warm=2)
+    # RoI crop at the RCNN shape: 64 boxes per frame, R=512, C=288 features (rcnn_multiclass.config:42,297)
+    from heterofusionrcnn_amd import modules
+    nroi = 64 * B
+    b3 = torch.zeros(nroi, 7, device="cuda")
+    b3[:, 0] = torch.from_numpy(rng.uniform(-35, 35, nroi).astype(np.float32)).cuda()
+    b3[:, 1] = 3.0
+    b3[:, 2] = torch.from_numpy(rng.uniform(5, 65, nroi).astype(np.float32)).cuda()
+    b3[:, 3:6] = torch.tensor([5.9, 3.6, 8.0], device="cuda")       # 3.9 x 1.6 car + 1 m context each side
+    b3[:, 6] = torch.from_numpy(rng.uniform(-np.pi, np.pi, nroi).astype(np.float32)).cuda()
+    boxes8 = modules.box_3d_to_box_8co(b3).contiguous()
+    box_ind = (torch.arange(nroi, device="cuda") // 64).to(torch.int32)
+    fts = torch.randn(B, N0, 288, device="cuda")
+    inten = torch.rand(B, N0, 1, device="cuda")
+    msk = torch.rand(B, N0, device="cuda") < 0.1
+    t["pc_crop_512roi_R512_C288_us"] = time_op(lambda: hf.pc_crop_and_sample(xyz, fts, inten, msk, boxes8, box_ind, 512),
+                                               iters=10, warm=2)
+    t["pc_crop_out_GBs"] = nroi * 512 * (3 + 288 + 1) * 4 / t["pc_crop_512roi_R512_C288_us"] / 1e3
     return {k: round(v, 3) for k, v in t.items()}
 
 

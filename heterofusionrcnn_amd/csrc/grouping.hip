@@ -534,22 +534,28 @@ __global__ void group_point_grad_kernel(int n, int c, long long rows_per_batch, 
 constexpr int kKnnThreads = 256;
 constexpr int kKnnTile = 1024;
 
+// PARTS lanes share one query: lane `part` takes the tile points c == part (mod PARTS) and keeps its own
+// sorted list; part 0 then merges the PARTS lists by (distance, index).  More parts = more waves in flight
+// when there are few queries (4096 queries x 8 clouds are only 512 waves with one thread per query).
+template <int PARTS>
 __global__ __launch_bounds__(kKnnThreads) void knn_kernel(int n, int m, int k, const float *__restrict__ xyz1,
                                                           const float *__restrict__ xyz2, float *__restrict__ val,
                                                           int *__restrict__ idx)
 {
+    constexpr int QB = kKnnThreads / PARTS;  // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *tile = reinterpret_cast<float *>(smem_raw);        // kKnnTile*3
     float *bd = tile + kKnnTile * 3;                          // k * kKnnThreads, column per thread
     int *bi = reinterpret_cast<int *>(bd + static_cast<size_t>(k) * kKnnThreads);
     const int t = threadIdx.x, bb = blockIdx.y;
-    const int j = blockIdx.x * kKnnThreads + t;
+    const int ql = t % QB, part = t / QB;
+    const int j = blockIdx.x * QB + ql;
     const float *p1 = xyz1 + static_cast<size_t>(bb) * n * 3;
     const float *p2 = xyz2 + static_cast<size_t>(bb) * m * 3;
     const bool live = j < m;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (live) { qx = p2[j * 3]; qy = p2[j * 3 + 1]; qz = p2[j * 3 + 2]; }
-    for (int s = 0; s < k; ++s) { bd[s * kKnnThreads + t] = INFINITY; bi[s * kKnnThreads + t] = 0; }
+    for (int s = 0; s < k; ++s) { bd[s * kKnnThreads + t] = INFINITY; bi[s * kKnnThreads + t] = 0x7fffffff; }
     float worst = INFINITY;  // bd[k-1]
     for (int base = 0; base < n; base += kKnnTile) {
         const int tn = min(kKnnTile, n - base);
@@ -557,10 +563,10 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(int n, int m, int k, c
         for (int e = t; e < tn * 3; e += kKnnThreads) tile[e] = p1[static_cast<size_t>(base) * 3 + e];
         __syncthreads();
         if (!live) continue;
-        for (int c = 0; c < tn; ++c) {
+        for (int c = part; c < tn; c += PARTS) {
             const float dx = qx - tile[c * 3], dy = qy - tile[c * 3 + 1], dz = qz - tile[c * 3 + 2];
             const float d = dx * dx + dy * dy + dz * dz;
-            if (d < worst) {  // strict: an equal distance with a higher index never displaces
+            if (d < worst) {  // strict: inside one part indices ascend, an equal distance never displaces
                 int pos = k - 1;
                 while (pos > 0 && bd[(pos - 1) * kKnnThreads + t] > d) {
                     bd[pos * kKnnThreads + t] = bd[(pos - 1) * kKnnThreads + t];
@@ -573,10 +579,39 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(int n, int m, int k, c
             }
         }
     }
-    if (live) {
+    __syncthreads();
+    if (PARTS > 1 && live && part == 0) {
+        // merge the other parts' lists into mine, ordered by (distance, index)
+        for (int p = 1; p < PARTS; ++p) {
+            const int ot = p * QB + ql;
+            for (int s = 0; s < k; ++s) {
+                const float d = bd[s * kKnnThreads + ot];
+                const int id = bi[s * kKnnThreads + ot];
+                const float wd = bd[(k - 1) * kKnnThreads + t];
+                const int wi = bi[(k - 1) * kKnnThreads + t];
+                if (!(d < wd || (d == wd && id < wi))) break;  // the rest of that list is no better
+                int pos = k - 1;
+                while (pos > 0) {
+                    const float pd = bd[(pos - 1) * kKnnThreads + t];
+                    const int pi = bi[(pos - 1) * kKnnThreads + t];
+                    if (!(pd > d || (pd == d && pi > id))) break;
+                    bd[pos * kKnnThreads + t] = pd;
+                    bi[pos * kKnnThreads + t] = pi;
+                    --pos;
+                }
+                bd[pos * kKnnThreads + t] = d;
+                bi[pos * kKnnThreads + t] = id;
+            }
+        }
+    }
+    if (live && part == 0) {
         float *ov = val + (static_cast<size_t>(bb) * m + j) * k;
         int *oi = idx + (static_cast<size_t>(bb) * m + j) * k;
-        for (int s = 0; s < k; ++s) { ov[s] = bd[s * kKnnThreads + t]; oi[s] = bi[s * kKnnThreads + t]; }
+        for (int s = 0; s < k; ++s) {
+            const int id = bi[s * kKnnThreads + t];
+            ov[s] = bd[s * kKnnThreads + t];
+            oi[s] = id == 0x7fffffff ? 0 : id;
+        }
     }
 }
 
@@ -672,6 +707,8 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
     if (nslab > m / 64) nslab = m / 64;
     if (nslab < 1) nslab = 1;
     nslab = env_int("HF_QBP_SLABS", nslab);      // diagnostics only
+    qcap = env_int("HF_QBP_QCAP", qcap);         // diagnostics only (LDS geometry)
+    ccap = env_int("HF_QBP_CCAP", ccap);
     const int stop = env_int("HF_QBP_STOP", 0);  // diagnostics only: early exit after phase N (outputs invalid)
     const size_t lds = slab_lds_bytes(nsample, qcap, ccap);
     dim3 grid(b, nslab);
@@ -755,11 +792,21 @@ HF_API int hf_knn_point(int b, int n, int m, int k, const float *xyz1, const flo
     if (b == 0 || m == 0) return HF_OK;
     const size_t lds = sizeof(float) * kKnnTile * 3 + (sizeof(float) + sizeof(int)) * static_cast<size_t>(k) * kKnnThreads;
     if (lds > 150 * 1024 || b > 65535) return HF_EINVAL;  // k <= 67 (the reference uses 8..32)
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
-    hipLaunchKernelGGL(knn_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, as_stream(stream), n, m, k,
-                       xyz1, xyz2, val, idx);
+    hipStream_t st = as_stream(stream);
+    // enough waves to fill the chip: one thread per query when there are many queries, else 4 or 16 lanes per query
+    const long long queries = static_cast<long long>(b) * m;
+#define HF_KNN_LAUNCH(P)                                                                                              \
+    do {                                                                                                              \
+        if (lds > 48 * 1024)                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_kernel<P>),                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));             \
+        hipLaunchKernelGGL((knn_kernel<P>), dim3(div_up(m, kKnnThreads / P), b), dim3(kKnnThreads), lds, st, n, m, k,   \
+                           xyz1, xyz2, val, idx);                                                                     \
+    } while (0)
+    if (queries >= 256 * 1024) HF_KNN_LAUNCH(1);
+    else if (queries >= 64 * 1024) HF_KNN_LAUNCH(4);
+    else HF_KNN_LAUNCH(16);
+#undef HF_KNN_LAUNCH
     return launch_status();
 }
 
