@@ -183,7 +183,18 @@ def per_op_table(hf, xyz):
     t["pc_crop_512roi_R512_C288_us"] = time_op(lambda: hf.pc_crop_and_sample(xyz, fts, inten, msk, boxes8, box_ind, 512),
                                                iters=10, warm=2)
     t["pc_crop_out_GBs"] = nroi * 512 * (3 + 288 + 1) * 4 / t["pc_crop_512roi_R512_C288_us"] / 1e3
+    # two-stage inference flow of BASELINE config 5 (RPN -> NMS -> crop -> RCNN -> NMS), random weights
+    from heterofusionrcnn_amd.two_stage import TwoStageDetector
+    torch.manual_seed(0)
+    det = TwoStageDetector().cuda().eval()
+    us = time_op(lambda: det(xyz, intensity_for_infer(xyz)), iters=3, warm=1)
+    t["two_stage_infer_ms_per_batch8"] = us / 1e3
+    t["two_stage_infer_frames_per_s"] = B / (us * 1e-6)
     return {k: round(v, 3) for k, v in t.items()}
+
+
+def intensity_for_infer(xyz):
+    return torch.zeros(xyz.shape[0], xyz.shape[1], 1, device=xyz.device)
 
 
 def cpu_baseline(frames):

@@ -19,13 +19,13 @@ from .sampling import farthest_point_sample, gather_point, prob_sample  # noqa: 
 from .grouping import (group_point, knn_point, query_ball_group, query_ball_point,  # noqa: E402
                        select_top_k)
 from .interpolate import three_interpolate, three_nn  # noqa: E402
-from .bev_iou import bev_iou, compute_bev_iou, nms_mask, oriented_nms  # noqa: E402
+from .bev_iou import bev_iou, compute_bev_iou, nms_mask, oriented_nms, oriented_nms_batched  # noqa: E402
 from .cropping import crop_and_resize, pc_crop_and_sample  # noqa: E402
 
 __all__ = [
     "farthest_point_sample", "gather_point", "prob_sample",
     "query_ball_point", "group_point", "query_ball_group", "select_top_k", "knn_point",
     "three_nn", "three_interpolate",
-    "compute_bev_iou", "bev_iou", "oriented_nms", "nms_mask",
+    "compute_bev_iou", "bev_iou", "oriented_nms", "oriented_nms_batched", "nms_mask",
     "pc_crop_and_sample", "crop_and_resize",
 ]

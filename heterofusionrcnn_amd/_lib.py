@@ -40,6 +40,7 @@ _SIGNATURES = {
     "hf_nms_mask": [_vp, _vp, _i, _f, _vp],
     "hf_oriented_nms_workspace": [_i],
     "hf_oriented_nms": [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp],
+    "hf_oriented_nms_batched": [_i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp],
     "hf_pc_crop_and_sample": [_vp] * 6 + [_i] * 6 + [_vp] * 6 + [_vp],
     "hf_pc_crop_and_sample_grad_fts": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "hf_bn_workspace": [ctypes.c_longlong, _i],

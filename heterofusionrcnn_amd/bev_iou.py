@@ -47,6 +47,25 @@ def oriented_nms(boxes, thresh, return_count=False):
     return (keep, num) if return_count else keep
 
 
+def oriented_nms_batched(boxes, thresh):
+    """boxes (F,N,5), each frame score-sorted -> (keep (F,N) int32, num_kept (F) int32): oriented_nms for every
+    frame of a batch in one launch pair (the reference loops frames with tf.map_fn, rpn_model.py:683-687)."""
+    thresh = float(thresh)
+    require(thresh >= 0, "Need nms_threshold >= 0, got %r" % thresh)
+    require(boxes.dim() == 3 and boxes.shape[0] > 0 and boxes.shape[1] > 0 and boxes.shape[2] == 5,
+            "oriented_nms_batched expects (F, N, 5) boxes shape")
+    boxes = dev_tensor(boxes.detach(), torch.float32, "boxes")
+    f, n, _ = boxes.shape
+    L = _lib.lib()
+    ws_bytes = f * L.hf_oriented_nms_workspace(n)
+    ws = torch.empty((ws_bytes // 8,), dtype=torch.int64, device=boxes.device)
+    keep = torch.empty((f, n), dtype=torch.int32, device=boxes.device)
+    num = torch.empty((f,), dtype=torch.int32, device=boxes.device)
+    check(L.hf_oriented_nms_batched(f, ptr(boxes), n, thresh, ptr(keep), ptr(num), ptr(ws), ws_bytes, stream_ptr()),
+          "oriented_nms_batched")
+    return keep, num
+
+
 def nms_mask(boxes, thresh):
     """The raw suppression bit mask of oriented_nms_gpu (bev_iou.cpp:40): (N, ceil(N/64)) int64 words."""
     require(boxes.dim() == 2 and boxes.shape[0] > 0 and boxes.shape[1] == 5, "nms_mask expects (N, 5) boxes shape")

@@ -285,6 +285,9 @@ __global__ __launch_bounds__(kNmsThreads) void nms_mask_kernel(int n, float thre
 {
     const int row_t = blockIdx.y, col_t = blockIdx.x;
     if (UPPER_ONLY && col_t < row_t) return;  // never read by the sweep (bev_iou.cpp:100-103 starts at nblock)
+    // blockIdx.z = frame of a batched call: every frame has its own (n,5) boxes and (n, ceil(n/64)) mask
+    boxes += static_cast<size_t>(blockIdx.z) * n * 5;
+    mask += static_cast<size_t>(blockIdx.z) * n * ((n + 63) / 64);
     __shared__ TileShared sh;
     const int t = threadIdx.x;
     const int row_size = min(n - row_t * 64, 64), col_size = min(n - col_t * 64, 64);
@@ -322,6 +325,10 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, const u
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int *kept_list = reinterpret_cast<int *>(smem_raw);  // up to n kept box indices
+    // blockIdx.x = frame of a batched call
+    mask += static_cast<size_t>(blockIdx.x) * n * ((n + 63) / 64);
+    keep += static_cast<size_t>(blockIdx.x) * n;
+    if (num_kept) num_kept += blockIdx.x;
     __shared__ unsigned long long red[kSweepThreads / 64];
     __shared__ unsigned long long remv_word;
     __shared__ int kept_total;
@@ -429,20 +436,26 @@ HF_API size_t hf_oriented_nms_workspace(int n)
 HF_API int hf_oriented_nms(const float *boxes, int n, float thresh, int *keep, int *num_kept, void *workspace,
                            size_t workspace_bytes, hf_stream_t stream)
 {
+    return hf_oriented_nms_batched(1, boxes, n, thresh, keep, num_kept, workspace, workspace_bytes, stream);
+}
+
+HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float thresh, int *keep, int *num_kept,
+                                   void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
     // OrientedNMSOp: nms_threshold >= 0 (bev_iou.cpp:52), N > 0 (:65)
-    if (n <= 0 || !(thresh >= 0.0f) || !boxes || !keep) return HF_EINVAL;
-    if (!workspace || workspace_bytes < hf_oriented_nms_workspace(n)) return HF_EWORKSPACE;
+    if (frames <= 0 || frames > 65535 || n <= 0 || !(thresh >= 0.0f) || !boxes || !keep) return HF_EINVAL;
+    if (!workspace || workspace_bytes < static_cast<size_t>(frames) * hf_oriented_nms_workspace(n)) return HF_EWORKSPACE;
     const int cb = (n + 63) / 64;
     const size_t lds = sizeof(int) * static_cast<size_t>(n);  // kept list
     if (cb > 65535 || lds > 140 * 1024) return HF_EINVAL;     // n <= ~35 000 boxes (pre_nms_size is 9000)
     hipStream_t st = as_stream(stream);
     unsigned long long *mask = static_cast<unsigned long long *>(workspace);
-    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(cb, cb), dim3(kNmsThreads), 0, st, n, thresh, boxes, mask);
+    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(cb, cb, frames), dim3(kNmsThreads), 0, st, n, thresh, boxes, mask);
     int rc = launch_status();
     if (rc != HF_OK) return rc;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_sweep_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(kSweepThreads), lds, st, n, mask, keep, num_kept);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(frames), dim3(kSweepThreads), lds, st, n, mask, keep, num_kept);
     return launch_status();
 }

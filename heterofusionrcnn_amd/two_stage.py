@@ -1,0 +1,141 @@
+"""Two-stage inference flow (BASELINE config 5) on the HIP ops, in miniature and with random weights.
+
+What is restated from the reference is the DATA FLOW between the ops, not its network bodies:
+
+  RPN forward -> per-point scores + boxes            hf/core/models/rpn_model.py:585-642
+  top-k pre_nms_size, oriented NMS, nms_size         rpn_model.py:645-687, model_util.py:101-142
+  expand proposals by the pooling context            hf/core/models/rcnn_model.py:462-476
+  box corners -> pc_crop_and_sample(resize)          rcnn_model.py:478-489
+  canonical transform of the cropped points          rcnn_model.py:207-235
+  RCNN forward on (N_roi, R, .) -> scores + boxes    rcnn_model.py:505-730
+  per-frame oriented NMS (thresh 0.01, size 100)     rcnn_model.py:731-778
+
+Frames are independent: `run_sharded` splits them rank-strided over the process group and rank 0 collects
+the per-frame detections (no tensor collective), as the reference's single-process evaluator would
+(hf/experiments/run_inference.py:152) if it were sharded.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import dp, modules
+from .bev_iou import oriented_nms_batched
+from .cropping import pc_crop_and_sample
+
+
+def canonical_transform(pts, boxes_3d):
+    """rcnn_model.py:207-235: translate to the box centre, rotate by -ry about y.  pts (N,R,3), boxes (N,7)"""
+    shift = pts - boxes_3d[:, None, 0:3]
+    ry = -boxes_3d[:, 6]
+    c, s = torch.cos(ry)[:, None], torch.sin(ry)[:, None]
+    x = c * shift[:, :, 0] + s * shift[:, :, 2]
+    z = -s * shift[:, :, 0] + c * shift[:, :, 2]
+    return torch.stack([x, shift[:, :, 1], z], dim=2)
+
+
+def expand_proposals(proposals, context):
+    """rcnn_model.py:462-476: sizes grow by 2*context, the (bottom-centre) y moves down by context"""
+    out = proposals.clone()
+    out[:, 1] = proposals[:, 1] + context
+    out[:, 3:6] = proposals[:, 3:6] + 2 * context
+    return out
+
+
+class BoxHead(nn.Module):
+    """per-point / per-RoI score and a box decoded around an anchor position (stand-in for the bin-based heads)"""
+
+    def __init__(self, cin, mean_size=(3.9, 1.6, 1.5)):
+        super().__init__()
+        self.cls = nn.Linear(cin, 1)
+        self.reg = nn.Linear(cin, 7)
+        self.register_buffer("mean_size", torch.tensor(mean_size))
+
+    def forward(self, feats, anchors_xyz):
+        score = torch.sigmoid(self.cls(feats)).squeeze(-1)
+        r = self.reg(feats)
+        centre = anchors_xyz + torch.tanh(r[..., 0:3]) * 1.5
+        size = self.mean_size * torch.exp(torch.clamp(r[..., 3:6], -0.5, 0.5))
+        ry = math.pi * torch.tanh(r[..., 6:7])
+        return score, torch.cat([centre, size, ry], dim=-1)
+
+
+class TwoStageDetector(nn.Module):
+    def __init__(self, pre_nms_size=9000, rpn_nms_thresh=0.8, rpn_nms_size=100, roi_crop_size=512, context=1.0,
+                 rcnn_nms_thresh=0.01, rcnn_nms_size=100, rpn_feat=128):
+        super().__init__()
+        self.pre_nms_size, self.rpn_nms_thresh, self.rpn_nms_size = pre_nms_size, rpn_nms_thresh, rpn_nms_size
+        self.roi_crop_size, self.context = roi_crop_size, context
+        self.rcnn_nms_thresh, self.rcnn_nms_size = rcnn_nms_thresh, rcnn_nms_size
+        self.rpn = modules.PointnetSAFPStack(in_channel=1)
+        assert self.rpn.out_channel == rpn_feat
+        self.rpn_head = BoxHead(rpn_feat)
+        cin = rpn_feat + 1 + 1  # cropped features + intensity + foreground mask (rcnn_model.py:178-182, 505-520)
+        self.rcnn_sa1 = modules.PointnetSAModule(128, 0.4, 16, cin, [128, 128])
+        self.rcnn_sa2 = modules.PointnetSAModule(32, 0.8, 16, 128, [128, 256])
+        self.rcnn_sa3 = modules.PointnetSAModule(None, None, None, 256, [256, 512], group_all=True)
+        self.rcnn_head = BoxHead(512)
+
+    @torch.no_grad()
+    def rpn_stage(self, xyz, intensity):
+        feats = self.rpn(xyz, intensity)                                   # (B,N,C)
+        scores, boxes = self.rpn_head(feats, xyz)                          # (B,N), (B,N,7)
+        k = min(self.pre_nms_size, xyz.shape[1])
+        top_s, top_i = torch.topk(scores, k, dim=1)                        # rpn_model.py:647-655, sorted descending
+        top_b = torch.gather(boxes, 1, top_i.unsqueeze(-1).expand(-1, -1, 7))
+        # tf.map_fn(sb_nms_fn) over the frames (rpn_model.py:683-687) as ONE batched device NMS; the tail of each
+        # keep row repeats keep[0] (bev_iou.cpp:110-112), which is what fixed_num_proposal_nms relies on
+        bev = torch.stack([modules.boxes3d_to_bev(top_b[b]) for b in range(top_b.shape[0])])
+        keep, _ = oriented_nms_batched(bev.contiguous(), self.rpn_nms_thresh)
+        ind = keep[:, :self.rpn_nms_size].long()
+        proposals = torch.gather(top_b, 1, ind.unsqueeze(-1).expand(-1, -1, 7))
+        return feats, proposals, torch.gather(top_s, 1, ind), scores
+
+    @torch.no_grad()
+    def rcnn_stage(self, xyz, feats, intensity, point_scores, proposals):
+        b, n_prop, _ = proposals.shape
+        flat = proposals.reshape(-1, 7)
+        box_ind = torch.arange(b, device=xyz.device, dtype=torch.int32).repeat_interleave(n_prop)
+        boxes8 = modules.box_3d_to_box_8co(expand_proposals(flat, self.context)).contiguous()
+        fg_mask = point_scores > 0.5
+        crop_pts, crop_fts, crop_int, crop_mask, _, non_empty = pc_crop_and_sample(
+            xyz, feats.contiguous(), intensity, fg_mask, boxes8, box_ind, self.roi_crop_size)
+        pts_ct = canonical_transform(crop_pts, flat).contiguous()
+        pts_in = torch.cat([crop_fts, crop_int, crop_mask.unsqueeze(-1).float()], dim=-1)
+        x1, f1, _ = self.rcnn_sa1(pts_ct, pts_in)
+        x2, f2, _ = self.rcnn_sa2(x1, f1)
+        _, f3, _ = self.rcnn_sa3(x2, f2)
+        score, refined = self.rcnn_head(f3.squeeze(1), flat[:, 0:3])
+        score = score * non_empty.float()                                   # empty RoIs carry no evidence
+        detections = []
+        for i in range(b):                                                  # rcnn_model.py:731-778
+            s, bx = score[i * n_prop:(i + 1) * n_prop], refined[i * n_prop:(i + 1) * n_prop]
+            ind, n = modules.sb_nms(bx, s, self.rcnn_nms_thresh, self.rcnn_nms_size, fixed_num_proposal_nms=False)
+            ind = ind[:n].long()
+            detections.append({"boxes": bx[ind], "scores": s[ind]})
+        return detections
+
+    @torch.no_grad()
+    def forward(self, xyz, intensity):
+        feats, proposals, _, point_scores = self.rpn_stage(xyz, intensity)
+        return self.rcnn_stage(xyz, feats, intensity, point_scores, proposals)
+
+
+def run_sharded(model, frames_xyz, frames_intensity, ctx, frames_per_batch=8):
+    """frames_* are lists of per-frame tensors (all ranks hold the same list, as a shared dataset would);
+    each rank runs its rank-strided shard and rank 0 receives {frame_id: detections} from everyone."""
+    mine = dp.shard_frames(len(frames_xyz), ctx.rank, ctx.world)
+    out = {}
+    for i in range(0, len(mine), frames_per_batch):
+        ids = mine[i:i + frames_per_batch]
+        xyz = torch.stack([frames_xyz[j] for j in ids]).to(ctx.device)
+        inten = torch.stack([frames_intensity[j] for j in ids]).to(ctx.device)
+        for j, det in zip(ids, model(xyz, inten)):
+            out[j] = {k: v.cpu() for k, v in det.items()}
+    gathered = dp.gather_objects(out, ctx)
+    if ctx.rank != 0:
+        return None
+    merged = {}
+    for part in gathered:
+        merged.update(part)
+    return merged

@@ -140,6 +140,11 @@ int hf_nms_mask(const float *boxes, unsigned long long *mask, int boxes_num, flo
 size_t hf_oriented_nms_workspace(int n);
 int hf_oriented_nms(const float *boxes, int n, float thresh, int *keep, int *num_kept, void *workspace,
                     size_t workspace_bytes, hf_stream_t stream);
+/* The reference maps OrientedNMS over the frames of a batch with tf.map_fn (rpn_model.py:683-687), i.e. one
+ * op call (and one host round trip) per frame.  Batched form: boxes (frames, n, 5), keep (frames, n),
+ * num_kept (frames) or NULL, workspace = frames * hf_oriented_nms_workspace(n) bytes; one launch pair. */
+int hf_oriented_nms_batched(int frames, const float *boxes, int n, float thresh, int *keep, int *num_kept,
+                            void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
 /* ------------------------------------------------------------------- cropping/ */
 

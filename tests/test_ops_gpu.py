@@ -735,3 +735,49 @@ def test_sample_and_group_knn_mode(hf, oracle_mod):
     assert np.array_equal(host(idx), o_idx)
     assert np.array_equal(host(gxyz), oracle_mod.group_point(xyz, o_idx) - o_new[:, :, None, :])
     assert (host(idx)[:, :, 0] == oracle_mod.farthest_point_sample(128, xyz)).all()  # nearest neighbour = itself
+
+
+def test_two_stage_inference_flow(hf, oracle_mod):
+    """RPN -> top-k -> oriented NMS -> expand -> crop -> canonical transform -> RCNN -> NMS on 2 frames;
+    checks the hand-offs between the ops against the oracle (crop) and against their definitions"""
+    from heterofusionrcnn_amd import dp, modules
+    from heterofusionrcnn_amd.two_stage import TwoStageDetector, canonical_transform, expand_proposals, run_sharded
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    det = TwoStageDetector(pre_nms_size=2048, rpn_nms_size=24, roi_crop_size=128).cuda().eval()
+    xyz = dev(kitti_uniform(rng, 2, 16384))
+    inten = dev(rng.uniform(-.5, .5, (2, 16384, 1)).astype(np.float32))
+    feats, proposals, pscores, point_scores = det.rpn_stage(xyz, inten)
+    assert proposals.shape == (2, 24, 7) and torch.isfinite(proposals).all()
+    # proposals of a frame do not suppress each other at the RPN threshold
+    for b in range(2):
+        uniq = torch.unique(proposals[b], dim=0)
+        _, iou = hf.compute_bev_iou(modules.boxes3d_to_bev(uniq), modules.boxes3d_to_bev(uniq))
+        iou.fill_diagonal_(0)
+        assert (iou <= 0.8 + TOL).all()
+    # the crop hand-off equals the oracle's crop of the same expanded boxes
+    flat = proposals.reshape(-1, 7)
+    boxes8 = modules.box_3d_to_box_8co(expand_proposals(flat, 1.0)).contiguous()
+    box_ind = torch.arange(2, device="cuda", dtype=torch.int32).repeat_interleave(24)
+    fg = point_scores > 0.5
+    got = hf.pc_crop_and_sample(xyz, feats.contiguous(), inten, fg, boxes8, box_ind, 128)
+    want = oracle_mod.pc_crop_and_sample(host(xyz), host(feats), host(inten), host(fg), host(boxes8), host(box_ind), 128)
+    for g, w in zip(got, want):
+        assert np.array_equal(host(g), w)
+    # canonical transform: the box centre maps to the origin, distances are preserved
+    ct = canonical_transform(got[0], flat)
+    np.testing.assert_allclose(host(torch.norm(ct, dim=2)), host(torch.norm(got[0] - flat[:, None, :3], dim=2)), atol=1e-4)
+    dets = det(xyz, inten)
+    assert len(dets) == 2 and all(d["boxes"].shape[1] == 7 and len(d["boxes"]) == len(d["scores"]) <= 24 for d in dets)
+    ctx = dp.DPContext(0, 1, 0, torch.device("cuda", 0))
+    merged = run_sharded(det, [xyz[0], xyz[1]], [inten[0], inten[1]], ctx, frames_per_batch=2)
+    assert sorted(merged) == [0, 1] and torch.equal(merged[0]["boxes"], dets[0]["boxes"].cpu())
+
+
+def test_batched_nms_equals_per_frame(hf, oracle_mod):
+    rng = np.random.default_rng(8)
+    frames = np.stack([_clustered(rng, 30, 10) for _ in range(3)])
+    keep, num = hf.oriented_nms_batched(dev(frames), 0.7)
+    for f in range(3):
+        want, kept = oracle_mod.oriented_nms(frames[f], 0.7, return_count=True)
+        assert np.array_equal(host(keep[f]), want) and int(host(num)[f]) == kept
