@@ -241,6 +241,11 @@ def cpu_baseline(frames):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON result): library banners (RCCL prints its version table on
+    # stdout when the communicator is created) and stray prints are routed to stderr at the fd level.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -336,8 +341,10 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_frames)
     dp.shutdown(ctx)
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
 
 
 if __name__ == "__main__":

@@ -134,8 +134,10 @@ constexpr int kSlabZBins = 1024;      // bins along the second axis
 
 struct SlabShared {
     unsigned qmin[3], qmax[3];   // ordered-uint bbox of ALL queries of the cloud
-    unsigned rmin[3], rmax[3];   // bbox of this round's own queries
     int wsum[kSlabWaves];
+    int b0, b1;                  // first / last histogram bin of this slab (-1: none)
+    int pre0, pre1;              // queries before the slab / up to its end
+    int nq;                      // slot counter of the single-round collection
 };
 
 // per-wave DPP reduction, then ONE lane touches LDS.  (A same-address LDS atomic issued by all 64 lanes
@@ -154,13 +156,35 @@ __device__ __forceinline__ void wave_bbox_merge(const float lo[3], const float h
     }
 }
 
+// The queries of a cloud are visited four times in phase A (bbox, histogram, ownership, collection).  With
+// QPT > 0 a thread keeps its QPT strided queries in registers after the first visit (m <= QPT * 1024);
+// QPT == 0 re-reads them from global memory (any m).
+template <int QPT> struct QueryRegs { float x[QPT > 0 ? QPT : 1], y[QPT > 0 ? QPT : 1], z[QPT > 0 ? QPT : 1]; };
+
+template <int QPT, typename F>
+__device__ __forceinline__ void for_each_query(int m, const float *__restrict__ p2, const QueryRegs<QPT> &qr, F &&f)
+{
+    const int t = threadIdx.x;
+    if constexpr (QPT > 0) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int j = t + i * kSlabThreads;
+            if (j < m) f(i, j, qr.x[i], qr.y[i], qr.z[i]);
+        }
+    } else {
+        int i = 0;
+        for (int j = t; j < m; j += kSlabThreads, ++i) f(i, j, p2[j * 3 + 0], p2[j * 3 + 1], p2[j * 3 + 2]);
+    }
+}
+
 constexpr int kSlabPPT = 8;   // data points prefetched into registers per thread and super-step
 constexpr int kSlabG = 8;     // lanes cooperating on one query in phase D
+constexpr int kSlotBits = 12; // row entries carry the candidate's slot in the LDS buffer when n < 2^(31-12)
 
-template <bool GROUP>
+template <bool GROUP, int QPT>
 __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, int nslab, float radius, float thresh,
                                                                 int nsample, int qcap, int ccap, int stop,
-                                                                const float *__restrict__ xyz1,
+                                                                int slot_bits, const float *__restrict__ xyz1,
                                                                 const float *__restrict__ xyz2, int center,
                                                                 int *__restrict__ idx, int *__restrict__ pts_cnt,
                                                                 float *__restrict__ grouped)
@@ -191,18 +215,25 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
     if (stop == -1) return;
     // ---------------- A1: bbox of all queries ----------------
     if (t < 3) { sh.qmin[t] = 0xffffffffu; sh.qmax[t] = 0u; }
+    if (t == 3) { sh.b0 = -1; sh.b1 = -1; sh.pre0 = 0; sh.pre1 = 0; }
     hist[t] = 0;
     __syncthreads();
+    QueryRegs<QPT> qr;
     {
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for (int j = t; j < m; j += kSlabThreads) {
+        if constexpr (QPT > 0) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float v = p2[j * 3 + d];
-                lo[d] = fminf(lo[d], v);
-                hi[d] = fmaxf(hi[d], v);
+            for (int i = 0; i < QPT; ++i) {
+                const int j = t + i * kSlabThreads;
+                const int jj = j < m ? j : 0;
+                qr.x[i] = p2[jj * 3 + 0]; qr.y[i] = p2[jj * 3 + 1]; qr.z[i] = p2[jj * 3 + 2];
             }
         }
+        for_each_query<QPT>(m, p2, qr, [&](int, int, float qx, float qy, float qz) {
+            lo[0] = fminf(lo[0], qx); hi[0] = fmaxf(hi[0], qx);
+            lo[1] = fminf(lo[1], qy); hi[1] = fmaxf(hi[1], qy);
+            lo[2] = fminf(lo[2], qz); hi[2] = fmaxf(hi[2], qz);
+        });
         wave_bbox_merge(lo, hi, sh.qmin, sh.qmax);
     }
     __syncthreads();
@@ -222,7 +253,9 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
     };
 
     // ---------------- A2/A3: histogram -> quantile slab of every bin ----------------
-    for (int j = t; j < m; j += kSlabThreads) atomicAdd(&hist[abin(p2[j * 3 + ax])], 1);
+    for_each_query<QPT>(m, p2, qr, [&](int, int, float qx, float qy, float qz) {
+        atomicAdd(&hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))], 1);
+    });
     __syncthreads();
     if (stop == -3) return;
     const int hcount = hist[t];
@@ -233,20 +266,16 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
     __syncthreads();
     hist[t] = myslab;  // bin -> slab (monotone in the bin index)
     __syncthreads();
-
-    // ---------------- A4a: which queries are mine; rank them (any fixed order will do) ----------------
-    // own-flags of this thread's first 32 strided queries are cached in a bit mask
-    unsigned ownmask = 0;
-    int owncnt = 0;
-    {
-        int i = 0;
-        for (int j = t; j < m; j += kSlabThreads, ++i) {
-            const bool own = hist[abin(p2[j * 3 + ax])] == slab;
-            if (own) { ++owncnt; if (i < 32) ownmask |= 1u << i; }
-        }
+    // my slab is one contiguous run of bins [b0, b1]; its first / last bin publish the run and the number of
+    // queries before / up to it (the histogram prefix), so the slab's query count needs no second scan
+    if (myslab == slab) {
+        if (t == 0 || hist[t - 1] != slab) { sh.b0 = t; sh.pre0 = before; }
+        if (t == kSlabBins - 1 || hist[t + 1] != slab) { sh.b1 = t; sh.pre1 = before + hcount; }
     }
-    int nq_total;
-    const int rank0 = block_exclusive_scan(owncnt, sh.wsum, &nq_total);
+    if (t == 0) { sh.nq = 0; }
+    __syncthreads();
+    if (sh.b1 < 0) return;  // no bin maps to this slab (fewer distinct bins than slabs)
+    const int nq_total = sh.pre1 - sh.pre0;
     if (nq_total == 0) return;
     if (stop == 1) return;  // diagnostic phase timing only (HF_QBP_STOP), never set in production
 
@@ -256,46 +285,65 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
     for (int d = 0; d < 3; ++d) amax = fmaxf(amax, fmaxf(fabsf(qlo[d]), fabsf(qhi[d])));
     const float rp = radius * 1.001f + 1e-6f * amax;
 
+    // candidate box of the slab: along the slab axis the bin run grown by half a bin on each side (covers the
+    // fp32 rounding of the bin computation), on the other axes the extent of all queries; plus the radius pad
+    float blo[3], bhi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { blo[d] = qlo[d] - rp; bhi[d] = qhi[d] + rp; }
+    if (ascale > 0.0f) {
+        const float binw = 1.0f / ascale;
+        const float slo = alo + (static_cast<float>(sh.b0) - 0.5f) * binw - rp;
+        const float shi = alo + (static_cast<float>(sh.b1) + 1.5f) * binw + rp;
+        if (ax == 0) { blo[0] = fmaxf(blo[0], slo); bhi[0] = fminf(bhi[0], shi); }
+        else if (ax == 1) { blo[1] = fmaxf(blo[1], slo); bhi[1] = fminf(bhi[1], shi); }
+        else { blo[2] = fmaxf(blo[2], slo); bhi[2] = fminf(bhi[2], shi); }
+    }
+    // second axis: the wider of the other two
+    const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+    const int zx = (bhi[a1] - blo[a1]) >= (bhi[a2] - blo[a2]) ? a1 : a2;
+    const float zlo = blo[zx];
+    const float zext = bhi[zx] - blo[zx];
+    const float zsize = fmaxf(rp * 1.01f, zext / static_cast<float>(kSlabZBins - 2));
+    const float zscale = 1.0f / zsize;
+    auto zbin = [&](float v) -> int {
+        int bq = static_cast<int>((v - zlo) * zscale);
+        return bq < 0 ? 0 : (bq > kSlabZBins - 1 ? kSlabZBins - 1 : bq);
+    };
+
+    // ---------------- A4: collect my queries ----------------
+    // common case (they all fit one round): any unique slot will do -> a wave-aggregated LDS counter.
+    // otherwise: fixed ranks from a block scan so that the rounds partition the queries consistently.
+    const bool single = nq_total <= qcap;
+    unsigned ownmask = 0;
+    int owncnt = 0, rank0 = 0;
+    if (!single) {
+        for_each_query<QPT>(m, p2, qr, [&](int i, int, float qx, float qy, float qz) {
+            const bool own = hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))] == slab;
+            if (own) { ++owncnt; if (i < 32) ownmask |= 1u << i; }
+        });
+        rank0 = block_exclusive_scan(owncnt, sh.wsum, nullptr);
+    }
+
     for (int round0 = 0; round0 < nq_total; round0 += qcap) {
-        // ---------------- A4b: collect this round's own queries (ranks [round0, round0+qcap)) ----------------
-        if (t < 3) { sh.rmin[t] = 0xffffffffu; sh.rmax[t] = 0u; }
-        __syncthreads();
-        {
-            float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-            int rank = rank0, i = 0;
-            for (int j = t; j < m && rank < round0 + qcap && rank < rank0 + owncnt; j += kSlabThreads, ++i) {
+        if (single) {
+            for_each_query<QPT>(m, p2, qr, [&](int, int j, float qx, float qy, float qz) {
+                if (hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))] == slab)
+                    qbuf[atomicAdd(&sh.nq, 1)] = make_float4(qx, qy, qz, __int_as_float(j));
+            });
+        } else if (owncnt > 0) {
+            int rank = rank0;
+            for_each_query<QPT>(m, p2, qr, [&](int i, int j, float qx, float qy, float qz) {
                 bool own;
                 if (i < 32) own = (ownmask >> i) & 1u;
-                else own = hist[abin(p2[j * 3 + ax])] == slab;
-                if (!own) continue;
-                if (rank >= round0) {
-                    const float qx = p2[j * 3 + 0], qy = p2[j * 3 + 1], qz = p2[j * 3 + 2];
-                    qbuf[rank - round0] = make_float4(qx, qy, qz, __int_as_float(j));
-                    lo[0] = fminf(lo[0], qx); hi[0] = fmaxf(hi[0], qx);
-                    lo[1] = fminf(lo[1], qy); hi[1] = fmaxf(hi[1], qy);
-                    lo[2] = fminf(lo[2], qz); hi[2] = fmaxf(hi[2], qz);
-                }
+                else own = hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))] == slab;
+                if (!own) return;
+                if (rank >= round0 && rank < round0 + qcap) qbuf[rank - round0] = make_float4(qx, qy, qz, __int_as_float(j));
                 ++rank;
-            }
-            wave_bbox_merge(lo, hi, sh.rmin, sh.rmax);
+            });
         }
         __syncthreads();
         if (stop == 2) return;
         const int nq = min(qcap, nq_total - round0);
-        float blo[3], bhi[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { blo[d] = ord2f(sh.rmin[d]) - rp; bhi[d] = ord2f(sh.rmax[d]) + rp; }
-        // second axis: widest extent of this round's box among the other two
-        const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
-        const int zx = (bhi[a1] - blo[a1]) >= (bhi[a2] - blo[a2]) ? a1 : a2;
-        const float zlo = blo[zx];
-        const float zext = bhi[zx] - blo[zx];
-        const float zsize = fmaxf(rp * 1.01f, zext / static_cast<float>(kSlabZBins - 2));
-        const float zscale = 1.0f / zsize;
-        auto zbin = [&](float v) -> int {
-            int bq = static_cast<int>((v - zlo) * zscale);
-            return bq < 0 ? 0 : (bq > kSlabZBins - 1 ? kSlabZBins - 1 : bq);
-        };
         for (int q = t; q < nq; q += kSlabThreads) hits[q] = 0;
 
         // ---- C + D on the current candidate buffer (nc entries); called by all threads together ----
@@ -339,13 +387,13 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
                 for (int it = 0; it < iters; ++it) {
                     const int i = i0 + it * kSlabG + sub;
                     bool hit = false;
-                    int k = 0;
+                    int k = 0;  // row entry: (data index << kSlotBits) | slot in `sorted` -- ordered by data index
                     if (i < i1) {
                         const float4 c = sorted[i];
                         const float dx = qq.x - c.x, dy = qq.y - c.y, dz = qq.z - c.z;
                         const float s2 = dx * dx + dy * dy + dz * dz;
                         hit = s2 < thresh;
-                        k = __float_as_int(c.w);
+                        k = (__float_as_int(c.w) << slot_bits) | (slot_bits ? i : 0);
                     }
                     const unsigned long long bal = __ballot(hit);
                     if (bal == 0ull) continue;  // wave-uniform
@@ -374,6 +422,7 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
         };
 
         // ---------------- B: stream the data points through registers ----------------
+        int nflush = 0;  // flushes of this round: with exactly one, `sorted` still holds every row's candidates in E
         int nc = 0;  // candidates in the LDS buffer: every thread tracks the same value
         for (int base = 0; base < n; base += kSlabPPT * kSlabThreads) {
             float px[kSlabPPT], py[kSlabPPT], pz[kSlabPPT];
@@ -408,6 +457,7 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
                     if (nc + kSlabThreads > ccap) {
                         __syncthreads();
                         flush(nc);
+                        ++nflush;
                         nc = 0;
                     }
                     const int bit = (inmask >> u) & 1u;
@@ -424,8 +474,9 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
         }
         __syncthreads();
         if (stop == 3) return;
-        if (nc > 0) flush(nc);
+        if (nc > 0) { flush(nc); ++nflush; }
         if (stop == 5) return;
+        const bool from_lds = slot_bits != 0 && nflush == 1;  // uniform
 
         // ---------------- E: write this round's rows ----------------
         for (int q = t; q < nq; q += kSlabThreads) {
@@ -440,7 +491,7 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
                 const int q = e / nsample, c = e - q * nsample;
                 const int j = __float_as_int(qbuf[q].w);
                 const int h = min(hits[q], nsample);
-                idx[(static_cast<size_t>(bb) * m + j) * nsample + c] = h == 0 ? 0 : rows[q * rs + (c < h ? c : 0)];
+                idx[(static_cast<size_t>(bb) * m + j) * nsample + c] = h == 0 ? 0 : (rows[q * rs + (c < h ? c : 0)] >> slot_bits);
             }
         }
         if (GROUP) {
@@ -460,9 +511,14 @@ __global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, in
                     const float4 qq = qbuf[q];
                     const int j = __float_as_int(qq.w);
                     const int h = min(hits[q], nsample);
-                    const int k = h == 0 ? 0 : rows[q * rs + (c < h ? c : 0)];
-                    const float *src = p1 + static_cast<size_t>(k) * 3;
-                    v[u] = f3{ src[0], src[1], src[2] };
+                    const int packed = h == 0 ? 0 : rows[q * rs + (c < h ? c : 0)];
+                    if (from_lds && h != 0) {
+                        const float4 cc = sorted[packed & ((1 << kSlotBits) - 1)];  // same values as the cloud's
+                        v[u] = f3{ cc.x, cc.y, cc.z };
+                    } else {
+                        const float *src = p1 + static_cast<size_t>(packed >> slot_bits) * 3;
+                        v[u] = f3{ src[0], src[1], src[2] };
+                    }
                     cq[u] = f3{ qq.x, qq.y, qq.z };
                     dst[u] = ((static_cast<size_t>(bb) * m + j) * nsample + c) * 3;
                 }
@@ -712,17 +768,26 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
     const int stop = env_int("HF_QBP_STOP", 0);  // diagnostics only: early exit after phase N (outputs invalid)
     const size_t lds = slab_lds_bytes(nsample, qcap, ccap);
     dim3 grid(b, nslab);
+    // (data index, LDS slot) packed in one int: needs n < 2^19 and every slot < 2^12
+    const int slot_bits = (n < (1 << (31 - kSlotBits)) && ccap <= (1 << kSlotBits)) ? kSlotBits : 0;
+#define HF_SLAB_LAUNCH(G, Q)                                                                                          \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<G, Q>),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
+        hipLaunchKernelGGL((qbp_slab_kernel<G, Q>), grid, dim3(kSlabThreads), lds, st, n, m, nslab, radius, thresh,    \
+                           nsample, qcap, ccap, stop, slot_bits, xyz1, xyz2, center, idx, pts_cnt, grouped);         \
+    } while (0)
+    // queries held in registers when they fit (4 per thread up to m = 4096, 8 up to 8192)
     if (grouped) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL((qbp_slab_kernel<true>), grid, dim3(kSlabThreads), lds, st, n, m, nslab, radius, thresh,
-                           nsample, qcap, ccap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped);
+        if (m <= 4 * kSlabThreads) HF_SLAB_LAUNCH(true, 4);
+        else if (m <= 8 * kSlabThreads) HF_SLAB_LAUNCH(true, 8);
+        else HF_SLAB_LAUNCH(true, 0);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL((qbp_slab_kernel<false>), grid, dim3(kSlabThreads), lds, st, n, m, nslab, radius, thresh,
-                           nsample, qcap, ccap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped);
+        if (m <= 4 * kSlabThreads) HF_SLAB_LAUNCH(false, 4);
+        else if (m <= 8 * kSlabThreads) HF_SLAB_LAUNCH(false, 8);
+        else HF_SLAB_LAUNCH(false, 0);
     }
+#undef HF_SLAB_LAUNCH
     return launch_status();
 }
 

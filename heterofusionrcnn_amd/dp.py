@@ -26,7 +26,7 @@ class DPContext:
 
     @property
     def distributed(self):
-        return self.world > 1
+        return self.world > 1 or (dist.is_available() and dist.is_initialized())
 
 
 def init(backend=None):
@@ -41,7 +41,9 @@ def init(backend=None):
     device = torch.device("cuda", local_rank) if (use_cuda and backend == "nccl") else torch.device("cpu")
     if device.type == "cuda":
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    # HF_FORCE_DDP=1 joins a one-rank group too, so the whole DDP code path can be exercised on a single GPU
+    force = os.environ.get("HF_FORCE_DDP", "") == "1" and "MASTER_PORT" in os.environ
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kwargs = {"device_id": device} if device.type == "cuda" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
