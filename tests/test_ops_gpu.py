@@ -781,3 +781,82 @@ def test_batched_nms_equals_per_frame(hf, oracle_mod):
     for f in range(3):
         want, kept = oracle_mod.oriented_nms(frames[f], 0.7, return_count=True)
         assert np.array_equal(host(keep[f]), want) and int(host(num)[f]) == kept
+
+
+def test_fuzz_all_ops_against_oracle(hf, oracle_mod):
+    """seeded sweep over ragged shapes, radii and K for every op of the path; the ball query runs on both of its
+    kernels and FPS on all of its kernels (plain 256/512/1024 threads, bucketed).  Everything integer is bit-exact."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import box_3d_to_8co, random_boxes3d
+    rng = np.random.default_rng(2026)
+    for trial in range(24):
+        b = int(rng.integers(1, 4))
+        n = int(rng.choice([1, 7, 63, 64, 65, 500, 1023, 1025, 2500, 4097, 9000]))
+        m = int(rng.choice([1, 5, 64, 255, 257, 1000, 3000]))
+        scale = float(rng.choice([1.0, 10.0, 80.0]))
+        x1 = (rng.random((b, n, 3), dtype=np.float32) * scale - scale / 3).astype(np.float32)
+        x2 = (rng.random((b, m, 3), dtype=np.float32) * scale - scale / 3).astype(np.float32)
+        if n > 20:
+            x1[:, -5:] = x1[:, :5]                         # duplicates
+            x2[:, :min(m, 3)] = x1[:, :min(m, 3)]          # queries that coincide with data points
+        r = float(rng.choice([0.02, 0.1, 0.5, 2.0])) * scale / 4
+        ns = int(rng.choice([1, 3, 16, 32, 64, 100, 140]))
+        oi, oc = oracle_mod.query_ball_point(r, ns, x1, x2)
+        for mode in ("", "bruteforce"):
+            os.environ["HF_BALL_QUERY"] = mode
+            try:
+                idx, cnt, gx = hf.query_ball_group(r, ns, dev(x1), dev(x2), center=True)
+            finally:
+                os.environ.pop("HF_BALL_QUERY", None)
+            assert np.array_equal(host(idx), oi) and np.array_equal(host(cnt), oc), (trial, mode, b, n, m, r, ns)
+            assert np.array_equal(host(gx), oracle_mod.group_point(x1, oi) - x2[:, :, None, :]), (trial, mode)
+        # FPS on every kernel
+        mm = int(min(n + 3, rng.choice([1, 2, 17, 128, 700])))
+        want = oracle_mod.farthest_point_sample(mm, x1)
+        variants = [("plain", "1024"), ("plain", "512"), ("bucket", "0")] + ([("plain", "256")] if n <= 4096 else [])
+        for mode, nt in variants:
+            os.environ["HF_FPS"], os.environ["HF_FPS_THREADS"] = mode, nt
+            try:
+                got = hf.farthest_point_sample(mm, dev(x1))
+            finally:
+                os.environ.pop("HF_FPS", None); os.environ.pop("HF_FPS_THREADS", None)
+            assert np.array_equal(host(got), want), (trial, mode, nt, b, n, mm)
+        # three_nn / kNN (x1 as known / data, x2 as unknown / queries)
+        d3, i3 = hf.three_nn(dev(x2), dev(x1))
+        od3, oi3 = oracle_mod.three_nn(x2, x1)
+        assert np.array_equal(host(i3), oi3) and np.array_equal(host(d3), od3), (trial, "three_nn")
+        k = int(min(n, rng.choice([1, 4, 8, 33])))
+        kv, ki = hf.knn_point(k, dev(x1), dev(x2))
+        okv, oki = oracle_mod.knn_point(k, x1, x2)
+        assert np.array_equal(host(ki), oki) and np.array_equal(host(kv), okv), (trial, "knn", n, m, k)
+        # group / interpolate with random channel counts
+        c = int(rng.choice([1, 2, 4, 12, 33]))
+        feats = rng.standard_normal((b, n, c)).astype(np.float32)
+        assert np.array_equal(host(hf.group_point(dev(feats), dev(oi))), oracle_mod.group_point(feats, oi))
+        w = rng.random((b, m, 3), dtype=np.float32)
+        assert np.array_equal(host(hf.three_interpolate(dev(feats), dev(oi3), dev(w))),
+                              oracle_mod.three_interpolate(feats, oi3, w))
+    # crop + NMS + IoU on random box sets
+    for trial in range(6):
+        bsz, p = int(rng.integers(1, 4)), int(rng.choice([100, 1000, 4000]))
+        pts = kitti_uniform(rng, bsz, p)
+        pts[:, :, 1] = rng.uniform(0, 2, (bsz, p)).astype(np.float32)
+        c = int(rng.choice([1, 4, 7]))
+        fts = rng.standard_normal((bsz, p, c)).astype(np.float32)
+        inten = rng.random((bsz, p, 1), dtype=np.float32)
+        msk = rng.random((bsz, p)) < 0.3
+        nb = int(rng.integers(1, 20))
+        b3 = random_boxes3d(rng, nb)
+        b3[:, 1] = 2.2
+        b3[:, 3:6] += rng.uniform(0, 30, (nb, 1)).astype(np.float32) * np.array([1, 1, 0.2], np.float32)
+        boxes = box_3d_to_8co(b3)
+        bi = rng.integers(0, bsz, nb).astype(np.int32)
+        rsz = int(rng.choice([1, 8, 100]))
+        got = hf.pc_crop_and_sample(dev(pts), dev(fts), dev(inten), dev(msk), dev(boxes), dev(bi), rsz)
+        want = oracle_mod.pc_crop_and_sample(pts, fts, inten, msk, boxes, bi, rsz)
+        for g, wv in zip(got, want):
+            assert np.array_equal(host(g), wv), ("crop", trial)
+        bev = _clustered(rng, max(1, nb), 7)
+        _, iou = hf.compute_bev_iou(dev(bev), dev(bev[:5]))
+        np.testing.assert_allclose(host(iou), oracle_mod.compute_bev_iou(bev, bev[:5])[1], rtol=0, atol=TOL)
