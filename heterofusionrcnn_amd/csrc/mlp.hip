@@ -245,12 +245,13 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                  const float *__restrict__ mean, const float *__restrict__ invstd,
                                  const float *__restrict__ dgamma, const float *__restrict__ dbeta, int relu,
-                                 float *__restrict__ dx)
+                                 float *__restrict__ dx, float *__restrict__ colsum_partial)
 {
+    extern __shared__ float smem[];
     const int t = threadIdx.x;
     const int cvec = t % cv, rsub = t / cv;
     const float inv_r = 1.0f / static_cast<float>(rows);
-    float a[VEC], b[VEC], mu[VEC], is[VEC], c1[VEC], c2[VEC];
+    float a[VEC], b[VEC], mu[VEC], is[VEC], c1[VEC], c2[VEC], cs[VEC], unused[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         const int ch = cvec * VEC + i;
@@ -259,6 +260,7 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
         b[i] = beta[ch] - mu[i] * a[i];
         c1[i] = dbeta[ch] * inv_r;
         c2[i] = dgamma[ch] * inv_r;
+        cs[i] = 0.f; unused[i] = 0.f;
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
@@ -272,10 +274,29 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
             float dh = vget<VEC>(g, i);
             if (relu && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
             const float xhat = (xv - mu[i]) * is[i];
-            vset<VEC>(o, i, a[i] * (dh - c1[i] - xhat * c2[i]));
+            const float d = a[i] * (dh - c1[i] - xhat * c2[i]);
+            cs[i] += d;
+            vset<VEC>(o, i, d);
         }
         stv<VEC>(dx + r * c + cvec * VEC, o);
     }
+    if (colsum_partial) {  // column sums of dx = the bias gradient of the Linear that produced x
+        reduce_rows<VEC>(cs, unused, cv, rpb, cvec, rsub, smem);
+        if (rsub == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                colsum_partial[(static_cast<size_t>(cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = cs[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_colsum_finalize_kernel(int c, int nblk, const float *__restrict__ partial,
+                                                                 float *__restrict__ colsum)
+{
+    const int ch = blockIdx.x;
+    double s, q;
+    bn_reduce_channel(partial, c, nblk, ch, s, q);
+    if (threadIdx.x == 0) colsum[ch] = static_cast<float>(s);
 }
 
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
@@ -337,7 +358,7 @@ HF_API int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const floa
 
 HF_API int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
                           const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
-                          float *dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+                          float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream)
 {
     if (rows <= 0 || c <= 0 || c > 4096 || !x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma ||
         !dbeta)
@@ -355,11 +376,14 @@ HF_API int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
                            g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, partial, dgamma, dbeta);
+    float *cpart = dx_colsum ? partial : nullptr;  // the reduce partials were consumed by the finalize kernel above
     if (g.vec == 4)
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx);
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart);
     else
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx);
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart);
+    if (dx_colsum)
+        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, cpart, dx_colsum);
     return launch_status();
 }

@@ -40,9 +40,69 @@ class _BNReLUTrain(torch.autograd.Function):
         dbeta = torch.empty_like(beta)
         ws, nbytes = _workspace(rows, c, x.device)
         check(_lib.lib().hf_bn_relu_bwd(rows, c, ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
-                                        1 if ctx.relu else 0, ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes,
+                                        1 if ctx.relu else 0, ptr(dx), ptr(dgamma), ptr(dbeta), None, ptr(ws), nbytes,
                                         stream_ptr()), "bn_relu_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def _splitk_wgrad(g, x, chunk=4096):
+    """dW = g^T x for tall-skinny g (R,Cout), x (R,Cin): the reduction over R split into chunks (a batched GEMM
+    that fills the chip) instead of one workgroup walking all R rows (see modules._TallSkinnyLinear)."""
+    r = x.shape[0]
+    if r < 32 * chunk or g.shape[1] * x.shape[1] > 512 * 512:
+        return g.t() @ x
+    main = (r // chunk) * chunk
+    gw = torch.bmm(g[:main].view(-1, chunk, g.shape[1]).transpose(1, 2), x[:main].view(-1, chunk, x.shape[1])).sum(dim=0)
+    if main < r:
+        gw = gw + g[main:].t() @ x[main:]
+    return gw
+
+
+class _LinearBNReLU(torch.autograd.Function):
+    """One autograd node for tf_util.conv2d([1,1], bn=True): z = x W^T + b; y = relu(bn(z)).
+    Saves x and z only (y is never needed again); the BN backward pass also returns the column sums of dz,
+    which ARE the bias gradient -- no separate reduction over the (R, Cout) gradient tensor."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        rows, cout = x.shape[0], weight.shape[0]
+        z = torch.addmm(bias, x, weight.t())
+        y = torch.empty_like(z)
+        mean = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        ws, nbytes = _workspace(rows, cout, x.device)
+        check(_lib.lib().hf_bn_relu_fwd_train(rows, cout, ptr(z), ptr(gamma), ptr(beta), eps, momentum,
+                                              ptr(running_mean), ptr(running_var), 1 if relu else 0, ptr(y),
+                                              ptr(mean), ptr(invstd), ptr(ws), nbytes, stream_ptr()),
+              "bn_relu_fwd_train")
+        ctx.save_for_backward(x, weight, z, gamma, beta, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, gamma, beta, mean, invstd = ctx.saved_tensors
+        rows, cout = z.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        dbias = torch.empty_like(beta)
+        ws, nbytes = _workspace(rows, cout, z.device)
+        check(_lib.lib().hf_bn_relu_bwd(rows, cout, ptr(z), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
+                                        1 if ctx.relu else 0, ptr(dz), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws),
+                                        nbytes, stream_ptr()), "bn_relu_bwd")
+        dx = dz @ weight if ctx.needs_input_grad[0] else None
+        dw = _splitk_wgrad(dz, x)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
+
+
+def linear_bn_relu(x, weight, bias, bn):
+    """x (R, Cin) -> relu(bn(x W^T + b)) with `bn` a BatchNormReLU module (training mode: fused node)"""
+    if bn.training:
+        return _LinearBNReLU.apply(x.contiguous(), weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.eps, bn.momentum, bn.relu)
+    return bn(torch.addmm(bias, x, weight.t()))
 
 
 class BatchNormReLU(nn.Module):

@@ -22,7 +22,7 @@ import torch.nn as nn
 from .grouping import group_point, knn_point, query_ball_group, query_ball_point
 from .interpolate import three_interpolate, three_nn
 from .sampling import farthest_point_sample, gather_point
-from .mlp import BatchNormReLU
+from .mlp import BatchNormReLU, linear_bn_relu
 from .bev_iou import compute_bev_iou as _compute_bev_iou, oriented_nms as _oriented_nms
 
 
@@ -81,11 +81,13 @@ class SharedMLPLayer(nn.Module):
 
     def forward(self, x):
         shape = x.shape
-        y = tall_skinny_linear(x.reshape(-1, shape[-1]), self.fc.weight, self.fc.bias)
+        rows = x.reshape(-1, shape[-1])
         if self.bn is not None:
-            y = self.bn(y)
-        elif self.relu:
-            y = torch.relu(y)
+            y = linear_bn_relu(rows, self.fc.weight, self.fc.bias, self.bn)  # one fused autograd node
+        else:
+            y = tall_skinny_linear(rows, self.fc.weight, self.fc.bias)
+            if self.relu:
+                y = torch.relu(y)
         return y.reshape(*shape[:-1], y.shape[-1])
 
 

@@ -189,10 +189,12 @@ int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const float *gam
 /* inference: y = relu?(gamma*invstd*(x-mean)+beta) with caller-provided mean / invstd */
 int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const float *gamma, const float *beta,
                         const float *mean, const float *invstd, int relu, float *y, hf_stream_t stream);
-/* backward of hf_bn_relu_fwd_train: dx (rows,c), dgamma (c), dbeta (c); the ReLU mask is recomputed from x */
+/* backward of hf_bn_relu_fwd_train: dx (rows,c), dgamma (c), dbeta (c); the ReLU mask is recomputed from x.
+ * dx_colsum (c floats, may be NULL) receives the column sums of dx: the bias gradient of the Linear / 1x1
+ * convolution that produced x, for free in the same pass. */
 int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
                    const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
-                   float *dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+                   float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
 #ifdef __cplusplus
 }

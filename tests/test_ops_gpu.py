@@ -860,3 +860,32 @@ def test_fuzz_all_ops_against_oracle(hf, oracle_mod):
         bev = _clustered(rng, max(1, nb), 7)
         _, iou = hf.compute_bev_iou(dev(bev), dev(bev[:5]))
         np.testing.assert_allclose(host(iou), oracle_mod.compute_bev_iou(bev, bev[:5])[1], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(140000, 32, 64), (5000, 7, 32), (300, 131, 196)])
+def test_fused_linear_bn_relu_node(hf, rows, cin, cout):
+    """modules.SharedMLPLayer (one fused Linear+BN+ReLU autograd node, split-K dW, bias gradient from the BN
+    backward pass) against nn.Linear + nn.BatchNorm1d + relu"""
+    from heterofusionrcnn_amd import modules
+    torch.manual_seed(rows)
+    layer = modules.SharedMLPLayer(cin, cout).cuda()
+    ref_fc = torch.nn.Linear(cin, cout).cuda()
+    ref_bn = torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.1).cuda()
+    with torch.no_grad():
+        ref_fc.weight.copy_(layer.fc.weight); ref_fc.bias.copy_(layer.fc.bias)
+        layer.bn.weight.uniform_(0.5, 1.5); layer.bn.bias.uniform_(-.5, .5)
+        ref_bn.weight.copy_(layer.bn.weight); ref_bn.bias.copy_(layer.bn.bias)
+    x1 = torch.randn(rows, cin, device="cuda", requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1 = torch.relu(ref_bn(ref_fc(x1)))
+    y2 = layer(x2)
+    torch.testing.assert_close(y2, y1, rtol=1e-4, atol=2e-5)
+    g = torch.randn_like(y1)
+    y1.backward(g); y2.backward(g)
+    torch.testing.assert_close(x2.grad, x1.grad, rtol=1e-3, atol=2e-5)
+    scale = float(ref_fc.weight.grad.abs().max())
+    torch.testing.assert_close(layer.fc.weight.grad, ref_fc.weight.grad, rtol=1e-3, atol=2e-4 * max(scale, 1.0))
+    torch.testing.assert_close(layer.bn.weight.grad, ref_bn.weight.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(layer.bn.bias.grad, ref_bn.bias.grad, rtol=1e-3, atol=1e-2)
+    # the bias of a Linear feeding a batch norm has an analytically zero gradient: both are rounding noise
+    assert layer.fc.bias.grad.abs().max() < 1e-2 and ref_fc.bias.grad.abs().max() < 1e-2
