@@ -299,6 +299,151 @@ __global__ __launch_bounds__(256) void bn_colsum_finalize_kernel(int c, int nblk
     if (threadIdx.x == 0) colsum[ch] = static_cast<float>(s);
 }
 
+// ------------------------------------------------------------------------------------------
+// BN + ReLU + max over the K rows of a group, fused (the tail of a set-abstraction MLP:
+// tf_util.conv2d(..., bn=True) followed by tf.reduce_max(axis=[2]), pointnet_util.py:156-176).
+// The normalised activation (G*K, C) is never written: the forward pass reads z once and keeps the
+// per-(group, channel) maximum and its row; the backward pass rebuilds the one-hot dy from that row.
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void bn_pool_fwd_kernel(long long groups, int k, int c, int cv, int rpb, long long groups_per_block,
+                                   const float *__restrict__ z, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, const float *__restrict__ mean,
+                                   const float *__restrict__ invstd, float *__restrict__ pooled,
+                                   unsigned char *__restrict__ argmax)
+{
+    const int t = threadIdx.x;
+    const int cvec = t % cv, rsub = t / cv;
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int ch = cvec * VEC + i;
+        a[i] = gamma[ch] * invstd[ch];
+        b[i] = beta[ch] - mean[ch] * a[i];
+    }
+    const long long g0 = blockIdx.x * groups_per_block;
+    const long long g1 = g0 + groups_per_block < groups ? g0 + groups_per_block : groups;
+    for (long long g = g0 + rsub; g < g1; g += rpb) {
+        float best[VEC];
+        int bk[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { best[i] = -1.0f; bk[i] = 0; }  // relu output is >= 0
+        const float *zg = z + (g * k) * c + cvec * VEC;
+        for (int kk = 0; kk < k; ++kk) {
+            const typename VecT<VEC>::type v = ldv<VEC>(zg + static_cast<long long>(kk) * c);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float h = fmaxf(a[i] * vget<VEC>(v, i) + b[i], 0.0f);
+                if (h > best[i]) { best[i] = h; bk[i] = kk; }  // first maximum wins
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            pooled[g * c + cvec * VEC + i] = best[i];
+            if (argmax) argmax[g * c + cvec * VEC + i] = static_cast<unsigned char>(bk[i]);
+        }
+    }
+}
+
+// sparse reduction for the BN backward: dh is dpooled at the arg-max row (if the ReLU is active there), else 0
+template <int VEC>
+__global__ void bn_pool_bwd_reduce_kernel(long long groups, int k, int c, int cv, int rpb, long long groups_per_block,
+                                          const float *__restrict__ z, const float *__restrict__ dpooled,
+                                          const unsigned char *__restrict__ argmax, const float *__restrict__ gamma,
+                                          const float *__restrict__ beta, const float *__restrict__ mean,
+                                          const float *__restrict__ invstd, float *__restrict__ partial)
+{
+    extern __shared__ float smem[];
+    const int t = threadIdx.x;
+    const int cvec = t % cv, rsub = t / cv;
+    float a[VEC], b[VEC], mu[VEC], is[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int ch = cvec * VEC + i;
+        mu[i] = mean[ch]; is[i] = invstd[ch];
+        a[i] = gamma[ch] * is[i];
+        b[i] = beta[ch] - mu[i] * a[i];
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    const long long g0 = blockIdx.x * groups_per_block;
+    const long long g1 = g0 + groups_per_block < groups ? g0 + groups_per_block : groups;
+    for (long long g = g0 + rsub; g < g1; g += rpb) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int ch = cvec * VEC + i;
+            const int kk = argmax[g * c + ch];
+            const float xv = z[(g * k + kk) * c + ch];
+            float dh = dpooled[g * c + ch];
+            if (!(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
+            s1[i] += dh;
+            s2[i] += dh * ((xv - mu[i]) * is[i]);
+        }
+    }
+    reduce_rows<VEC>(s1, s2, cv, rpb, cvec, rsub, smem);
+    if (rsub == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            partial[(static_cast<size_t>(cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = s1[i];
+            partial[(static_cast<size_t>(c + cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = s2[i];
+        }
+    }
+}
+
+// dense dz over all G*K rows: dz = gamma*invstd*(dh - dbeta/R - xhat*dgamma/R), dh one-hot per (group, channel)
+template <int VEC>
+__global__ void bn_pool_bwd_dx_kernel(long long rows, int k, int c, int cv, int rpb, long long rows_per_block,
+                                      const float *__restrict__ z, const float *__restrict__ dpooled,
+                                      const unsigned char *__restrict__ argmax, const float *__restrict__ gamma,
+                                      const float *__restrict__ beta, const float *__restrict__ mean,
+                                      const float *__restrict__ invstd, const float *__restrict__ dgamma,
+                                      const float *__restrict__ dbeta, float *__restrict__ dz,
+                                      float *__restrict__ colsum_partial)
+{
+    extern __shared__ float smem[];
+    const int t = threadIdx.x;
+    const int cvec = t % cv, rsub = t / cv;
+    const float inv_r = 1.0f / static_cast<float>(rows);
+    float a[VEC], b[VEC], mu[VEC], is[VEC], c1[VEC], c2[VEC], cs[VEC], unused[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int ch = cvec * VEC + i;
+        mu[i] = mean[ch]; is[i] = invstd[ch];
+        a[i] = gamma[ch] * is[i];
+        b[i] = beta[ch] - mu[i] * a[i];
+        c1[i] = dbeta[ch] * inv_r;
+        c2[i] = dgamma[ch] * inv_r;
+        cs[i] = 0.f; unused[i] = 0.f;
+    }
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long long r = r0 + rsub; r < r1; r += rpb) {
+        const long long g = r / k;
+        const int kk = static_cast<int>(r - g * k);
+        const typename VecT<VEC>::type v = ldv<VEC>(z + r * c + cvec * VEC);
+        const typename VecT<VEC>::type dp = ldv<VEC>(dpooled + g * c + cvec * VEC);
+        typename VecT<VEC>::type o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float xv = vget<VEC>(v, i);
+            float dh = 0.0f;
+            if (argmax[g * c + cvec * VEC + i] == kk && a[i] * xv + b[i] > 0.0f) dh = vget<VEC>(dp, i);
+            const float xhat = (xv - mu[i]) * is[i];
+            const float d = a[i] * (dh - c1[i] - xhat * c2[i]);
+            cs[i] += d;
+            vset<VEC>(o, i, d);
+        }
+        stv<VEC>(dz + r * c + cvec * VEC, o);
+    }
+    if (colsum_partial) {
+        reduce_rows<VEC>(cs, unused, cv, rpb, cvec, rsub, smem);
+        if (rsub == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                colsum_partial[(static_cast<size_t>(cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = cs[i];
+        }
+    }
+}
+
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 }  // namespace hf
@@ -385,5 +530,79 @@ HF_API int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy
                            g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart);
     if (dx_colsum)
         hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, cpart, dx_colsum);
+    return launch_status();
+}
+
+HF_API int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z, const float *gamma, const float *beta,
+                                  int training, float eps, float momentum, float *running_mean, float *running_var,
+                                  float *mean, float *invstd, float *pooled, unsigned char *argmax, void *workspace,
+                                  size_t workspace_bytes, hf_stream_t stream)
+{
+    if (groups <= 0 || k <= 0 || k > 255 || c <= 0 || c > 4096 || !z || !gamma || !beta || !mean || !invstd || !pooled)
+        return HF_EINVAL;
+    const long long rows = groups * k;
+    hipStream_t st = as_stream(stream);
+    if (training) {
+        if (!argmax) return HF_EINVAL;
+        if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
+        BnGeom g = bn_geom(rows, c);
+        if (g.vec == 4 && !aligned16(z)) return HF_EINVAL;
+        float *partial = static_cast<float *>(workspace);
+        const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+        if (g.vec == 4)
+            hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                               g.rows_per_block, z, partial);
+        else
+            hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                               g.rows_per_block, z, partial);
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps, momentum,
+                           running_mean, running_var, mean, invstd);
+    }
+    BnGeom gg = bn_geom(groups, c);
+    if (gg.vec == 4 && !aligned16(z)) return HF_EINVAL;
+    if (gg.vec == 4)
+        hipLaunchKernelGGL((bn_pool_fwd_kernel<4>), dim3(gg.nblk), dim3(gg.threads), 0, st, groups, k, c, gg.cv, gg.rpb,
+                           gg.rows_per_block, z, gamma, beta, mean, invstd, pooled, argmax);
+    else
+        hipLaunchKernelGGL((bn_pool_fwd_kernel<1>), dim3(gg.nblk), dim3(gg.threads), 0, st, groups, k, c, gg.cv, gg.rpb,
+                           gg.rows_per_block, z, gamma, beta, mean, invstd, pooled, argmax);
+    return launch_status();
+}
+
+HF_API int hf_bn_relu_maxpool_bwd(long long groups, int k, int c, const float *z, const float *dpooled,
+                                  const unsigned char *argmax, const float *gamma, const float *beta,
+                                  const float *save_mean, const float *save_invstd, float *dz, float *dgamma,
+                                  float *dbeta, float *dz_colsum, void *workspace, size_t workspace_bytes,
+                                  hf_stream_t stream)
+{
+    if (groups <= 0 || k <= 0 || k > 255 || c <= 0 || c > 4096 || !z || !dpooled || !argmax || !gamma || !beta ||
+        !save_mean || !save_invstd || !dz || !dgamma || !dbeta)
+        return HF_EINVAL;
+    const long long rows = groups * k;
+    if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    BnGeom gg = bn_geom(groups, c);
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !(aligned16(z) && aligned16(dz) && aligned16(dpooled))) return HF_EINVAL;
+    const size_t lds_g = sizeof(float) * static_cast<size_t>(gg.threads) * 2 * gg.vec;
+    const size_t lds_r = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+    if (gg.vec == 4)
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<4>), dim3(gg.nblk), dim3(gg.threads), lds_g, st, groups, k, c, gg.cv,
+                           gg.rpb, gg.rows_per_block, z, dpooled, argmax, gamma, beta, save_mean, save_invstd, partial);
+    else
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<1>), dim3(gg.nblk), dim3(gg.threads), lds_g, st, groups, k, c, gg.cv,
+                           gg.rpb, gg.rows_per_block, z, dpooled, argmax, gamma, beta, save_mean, save_invstd, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, gg.nblk, partial, dgamma, dbeta);
+    float *cpart = dz_colsum ? partial : nullptr;
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_pool_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds_r, st, rows, k, c, g.cv, g.rpb,
+                           g.rows_per_block, z, dpooled, argmax, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dz,
+                           cpart);
+    else
+        hipLaunchKernelGGL((bn_pool_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds_r, st, rows, k, c, g.cv, g.rpb,
+                           g.rows_per_block, z, dpooled, argmax, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dz,
+                           cpart);
+    if (dz_colsum) hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, cpart, dz_colsum);
     return launch_status();
 }

@@ -131,3 +131,62 @@ class BatchNormReLU(nn.Module):
                                              ptr(self.running_mean), ptr(invstd), 1 if self.relu else 0, ptr(y),
                                              stream_ptr()), "bn_relu_fwd_eval")
         return y
+
+
+class _LinearBNReLUMaxPool(torch.autograd.Function):
+    """x (G*K, Cin) -> max over the K rows of each group of relu(bn(x W^T + b)): (G, Cout).
+    The tail of a set-abstraction MLP as one node; the (G*K, Cout) normalised activation and its gradient are
+    never materialised (the backward pass rebuilds the one-hot dy from the stored arg-max rows)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, k):
+        rows, cout = x.shape[0], weight.shape[0]
+        groups = rows // k
+        z = torch.addmm(bias, x, weight.t())
+        pooled = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
+        argmax = torch.empty((groups, cout), dtype=torch.uint8, device=x.device)
+        mean = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        ws, nbytes = _workspace(rows, cout, x.device)
+        check(_lib.lib().hf_bn_relu_maxpool_fwd(groups, k, cout, ptr(z), ptr(gamma), ptr(beta), 1, eps, momentum,
+                                                ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd),
+                                                ptr(pooled), ptr(argmax), ptr(ws), nbytes, stream_ptr()),
+              "bn_relu_maxpool_fwd")
+        ctx.save_for_backward(x, weight, z, gamma, beta, mean, invstd, argmax)
+        ctx.k = k
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, weight, z, gamma, beta, mean, invstd, argmax = ctx.saved_tensors
+        rows, cout = z.shape
+        groups = rows // ctx.k
+        dpooled = dpooled.contiguous()
+        dz = torch.empty_like(z)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        dbias = torch.empty_like(beta)
+        ws, nbytes = _workspace(rows, cout, z.device)
+        check(_lib.lib().hf_bn_relu_maxpool_bwd(groups, ctx.k, cout, ptr(z), ptr(dpooled), ptr(argmax), ptr(gamma),
+                                                ptr(beta), ptr(mean), ptr(invstd), ptr(dz), ptr(dgamma), ptr(dbeta),
+                                                ptr(dbias), ptr(ws), nbytes, stream_ptr()), "bn_relu_maxpool_bwd")
+        dx = dz @ weight if ctx.needs_input_grad[0] else None
+        dw = _splitk_wgrad(dz, x)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
+
+
+def linear_bn_relu_maxpool(x, weight, bias, bn, k):
+    """x (G*K, Cin), K rows per group -> (G, Cout); `bn` a BatchNormReLU module with relu=True"""
+    assert bn.relu and x.shape[0] % k == 0 and k <= 255
+    x = x.contiguous()
+    if bn.training:
+        return _LinearBNReLUMaxPool.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                          bn.eps, bn.momentum, k)
+    z = torch.addmm(bias, x, weight.t())
+    groups, cout = x.shape[0] // k, weight.shape[0]
+    pooled = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    check(_lib.lib().hf_bn_relu_maxpool_fwd(groups, k, cout, ptr(z), ptr(bn.weight), ptr(bn.bias), 0, bn.eps, bn.momentum,
+                                            None, None, ptr(bn.running_mean), ptr(invstd), ptr(pooled), None, None, 0,
+                                            stream_ptr()), "bn_relu_maxpool_fwd")
+    return pooled

@@ -22,7 +22,7 @@ import torch.nn as nn
 from .grouping import group_point, knn_point, query_ball_group, query_ball_point
 from .interpolate import three_interpolate, three_nn
 from .sampling import farthest_point_sample, gather_point
-from .mlp import BatchNormReLU, linear_bn_relu
+from .mlp import BatchNormReLU, linear_bn_relu, linear_bn_relu_maxpool
 from .bev_iou import compute_bev_iou as _compute_bev_iou, oriented_nms as _oriented_nms
 
 
@@ -172,8 +172,21 @@ class PointnetSAModule(nn.Module):
         else:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group(self.npoint, self.radius, self.nsample, xyz,
                                                                      points, self.knn, self.use_xyz)
-        new_points = self.mlp(new_points)
-        if self.pooling == "max":
+        last = self.mlp[-1]
+        fuse_pool = (self.pooling == "max" and last.bn is not None and last.relu and new_points.shape[2] <= 255 and
+                     new_points.is_cuda)
+        if fuse_pool:
+            # every layer but the last as usual; the last one fused with the max over the K grouped points
+            for layer in list(self.mlp)[:-1]:
+                new_points = layer(new_points)
+            bsz, npt, k, cin = new_points.shape
+            pooled = linear_bn_relu_maxpool(new_points.reshape(-1, cin), last.fc.weight, last.fc.bias, last.bn, k)
+            new_points = pooled.reshape(bsz, npt, 1, -1)
+        else:
+            new_points = self.mlp(new_points)
+        if fuse_pool:
+            pass
+        elif self.pooling == "max":
             new_points = new_points.max(dim=2, keepdim=True).values
         elif self.pooling == "avg":
             new_points = new_points.mean(dim=2, keepdim=True)

@@ -196,6 +196,22 @@ int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const
                    const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                    float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* BN + ReLU + max over the k rows of every group, fused: the tail of a set-abstraction MLP
+ * (tf_util.conv2d(..., bn=True) then tf.reduce_max(axis=[2]), pointnet_util.py:156-176).  z is (groups*k, c)
+ * pre-BN; pooled is (groups, c).  training != 0: batch statistics are computed here (and the running estimates
+ * updated) and written to mean / invstd, argmax (groups, c) bytes records the winning row of each maximum
+ * (k <= 255); training == 0: mean / invstd are inputs, argmax may be NULL.  The normalised (groups*k, c)
+ * activation is never materialised. */
+int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z, const float *gamma, const float *beta,
+                           int training, float eps, float momentum, float *running_mean, float *running_var,
+                           float *mean, float *invstd, float *pooled, unsigned char *argmax, void *workspace,
+                           size_t workspace_bytes, hf_stream_t stream);
+/* backward: dpooled (groups, c) -> dz (groups*k, c), dgamma, dbeta, and optionally the column sums of dz */
+int hf_bn_relu_maxpool_bwd(long long groups, int k, int c, const float *z, const float *dpooled,
+                           const unsigned char *argmax, const float *gamma, const float *beta, const float *save_mean,
+                           const float *save_invstd, float *dz, float *dgamma, float *dbeta, float *dz_colsum,
+                           void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -889,3 +889,50 @@ def test_fused_linear_bn_relu_node(hf, rows, cin, cout):
     torch.testing.assert_close(layer.bn.bias.grad, ref_bn.bias.grad, rtol=1e-3, atol=1e-2)
     # the bias of a Linear feeding a batch norm has an analytically zero gradient: both are rounding noise
     assert layer.fc.bias.grad.abs().max() < 1e-2 and ref_fc.bias.grad.abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("groups,k,cin,cout", [(4096, 32, 32, 64), (333, 17, 7, 5), (1024, 64, 128, 256), (50, 255, 16, 24)])
+def test_fused_linear_bn_relu_maxpool_node(hf, groups, k, cin, cout):
+    """mlp.linear_bn_relu_maxpool (Linear + BN + ReLU + max over the K grouped rows as one node; the dense
+    activation is never written) against nn.Linear + nn.BatchNorm1d + relu + max(dim=1); train and eval"""
+    from heterofusionrcnn_amd import modules
+    from heterofusionrcnn_amd.mlp import linear_bn_relu_maxpool
+    torch.manual_seed(groups + k)
+    layer = modules.SharedMLPLayer(cin, cout).cuda()
+    ref_fc = torch.nn.Linear(cin, cout).cuda()
+    ref_bn = torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.1).cuda()
+    with torch.no_grad():
+        ref_fc.weight.copy_(layer.fc.weight); ref_fc.bias.copy_(layer.fc.bias)
+        layer.bn.weight.uniform_(0.5, 1.5); layer.bn.bias.uniform_(-.5, .5)
+        ref_bn.weight.copy_(layer.bn.weight); ref_bn.bias.copy_(layer.bn.bias)
+    x1 = torch.randn(groups * k, cin, device="cuda")
+    # ball-query style padding: the tail rows of some groups repeat the group's first row (exact ties)
+    xv = x1.view(groups, k, cin)
+    xv[::3, k // 2:] = xv[::3, :1]
+    x1.requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1 = torch.relu(ref_bn(ref_fc(x1))).view(groups, k, cout).max(dim=1).values
+    y2 = linear_bn_relu_maxpool(x2, layer.fc.weight, layer.fc.bias, layer.bn, k)
+    torch.testing.assert_close(y2, y1, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(layer.bn.running_mean, ref_bn.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(layer.bn.running_var, ref_bn.running_var, rtol=1e-4, atol=1e-5)
+    g = torch.randn_like(y1)
+    y1.backward(g); y2.backward(g)
+    # which of several identical rows receives the gradient is a free choice: compare per-group sums over ties
+    # through quantities that do not depend on it (dW, dgamma, dbeta) and dx summed over identical rows
+    scale = float(ref_fc.weight.grad.abs().max())
+    torch.testing.assert_close(layer.fc.weight.grad, ref_fc.weight.grad, rtol=1e-3, atol=2e-4 * max(scale, 1.0))
+    torch.testing.assert_close(layer.bn.weight.grad, ref_bn.weight.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(layer.bn.bias.grad, ref_bn.bias.grad, rtol=1e-3, atol=1e-2)
+    d1 = x1.grad.view(groups, k, cin); d2 = x2.grad.view(groups, k, cin)
+    torch.testing.assert_close(d2[1::3], d1[1::3], rtol=1e-3, atol=2e-5)       # groups without ties: row by row
+    torch.testing.assert_close(d2[2::3], d1[2::3], rtol=1e-3, atol=2e-5)
+    tied = lambda d: torch.cat([d[::3, 1:k // 2], d[::3, :1] + d[::3, k // 2:].sum(1, keepdim=True)], dim=1)
+    torch.testing.assert_close(tied(d2), tied(d1), rtol=1e-3, atol=5e-5)
+    assert layer.fc.bias.grad.abs().max() < 1e-2
+    # eval: running statistics
+    layer.eval(); ref_bn.eval()
+    with torch.no_grad():
+        e1 = torch.relu(ref_bn(ref_fc(x1))).view(groups, k, cout).max(dim=1).values
+        e2 = linear_bn_relu_maxpool(x2.detach(), layer.fc.weight, layer.fc.bias, layer.bn, k)
+    torch.testing.assert_close(e2, e1, rtol=1e-4, atol=2e-5)
