@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-table", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the geometry ops inline instead of one step ahead")
+    ap.add_argument("--prefetch-depth", type=int, default=2, help="batches of geometry in flight (one HIP stream each)")
     ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
 
@@ -273,14 +274,14 @@ def main():
     torch.manual_seed(1234)  # same initial weights on every rank (the reference broadcasts from rank 0)
     model = modules.PointnetSAFPStack(in_channel=1, sa=SA, fp=FP).cuda()
     net = dp.wrap_model(model, ctx)                            # broadcast from rank 0 + gradient all-reduce (RCCL)
-    opt = torch.optim.Adam(net.parameters(), lr=dp.scaled_lr(1e-3, world))  # optimizer_builder.py:105
+    opt = torch.optim.Adam(net.parameters(), lr=dp.scaled_lr(1e-3, world), fused=True)  # optimizer_builder.py:105; one kernel for all tensors
 
     rng = np.random.default_rng(1000 + rank)                   # rank-sharded synthetic frames
     xyz = torch.from_numpy(kitti_uniform(rng, B, N0)).cuda()
     intensity = torch.from_numpy(rng.uniform(-0.5, 0.5, (B, N0, 1)).astype(np.float32)).cuda()
 
     from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
-    prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry)
+    prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth)
 
     def step():
         # the coordinate-only ops of the NEXT batch run on a side stream while this batch trains;
@@ -297,7 +298,8 @@ def main():
         return loss
 
     if prefetch is not None:
-        prefetch.submit(xyz)
+        for _ in range(prefetch.depth):
+            prefetch.submit(xyz)
     for _ in range(args.warmup):
         step()
 
@@ -326,7 +328,7 @@ def main():
             "config": {"workload": "SA+FP stack 16384->4096->1024->256, K=32, radii 0.5/1.0/2.0, B=8 frames per GPU, "
                                    "fwd+bwd+Adam, fp32 (BASELINE.json configs[1])",
                        "frames_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
-                       "geometry_prefetch_stream": prefetch is not None},
+                       "geometry_prefetch_depth": prefetch.depth if prefetch is not None else 0},
             "roofline": {"kernel": "query_ball_point+group_point fused (hf_query_ball_group_xyz), B=8 N=16384 M=4096 K=32",
                          "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,

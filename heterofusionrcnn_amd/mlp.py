@@ -45,10 +45,14 @@ class _BNReLUTrain(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
-def _splitk_wgrad(g, x, chunk=4096):
+def _splitk_wgrad(g, x, chunk=None):
     """dW = g^T x for tall-skinny g (R,Cout), x (R,Cin): the reduction over R split into chunks (a batched GEMM
-    that fills the chip) instead of one workgroup walking all R rows (see modules._TallSkinnyLinear)."""
+    that fills the chip) instead of one workgroup walking all R rows (see modules._TallSkinnyLinear).
+    Chunk sizes from scripts/gemm_pad_probe.py on MI355X: a plain GEMM with R = 65536, 128x196 outputs takes
+    230 us, 64 chunks of 1024 rows 46 us."""
     r = x.shape[0]
+    if chunk is None:
+        chunk = 4096 if r >= 131072 else 1024
     if r < 32 * chunk or g.shape[1] * x.shape[1] > 512 * 512:
         return g.t() @ x
     main = (r // chunk) * chunk

@@ -23,27 +23,44 @@ def _walk(obj, fn):
 
 
 class GeometryPrefetcher:
-    def __init__(self, geometry_fn, device=None):
+    """`depth` batches in flight, each on its own HIP stream (round robin), consumed in submission order.
+
+    One FPS chain (16384 -> 4096 -> 1024 -> 256) is ~5.6 ms of strictly sequential rounds on 8 CUs; once the
+    feature half of a step is shorter than that, a single side stream bounds the step.  With depth 2 the
+    geometry of batches i+1 and i+2 overlap each other as well as the training of batch i (16 of 256 CUs)."""
+
+    def __init__(self, geometry_fn, device=None, depth=1):
+        assert depth >= 1
         self.fn = geometry_fn
-        self.stream = torch.cuda.Stream(device=device)
-        self._pending = None
+        self.depth = depth
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
+        self._pending = []
+        self._turn = 0
+
+    @property
+    def stream(self):
+        return self.streams[0]
+
+    def __len__(self):
+        return len(self._pending)
 
     def submit(self, xyz):
-        """enqueue geometry_fn(xyz) on the side stream (xyz must already be produced on the current stream)"""
-        assert self._pending is None, "one batch in flight at a time"
+        """enqueue geometry_fn(xyz) on the next side stream (xyz must already be produced on the current stream)"""
+        assert len(self._pending) < self.depth, "at most `depth` batches in flight"
+        side = self.streams[self._turn % self.depth]
+        self._turn += 1
         main = torch.cuda.current_stream()
-        self.stream.wait_stream(main)  # xyz ready
-        with torch.cuda.stream(self.stream):
+        side.wait_stream(main)  # xyz ready
+        with torch.cuda.stream(side):
             geo = self.fn(xyz)
             done = torch.cuda.Event()
-            done.record(self.stream)
-        xyz.record_stream(self.stream)
-        self._pending = (geo, done)
+            done.record(side)
+        xyz.record_stream(side)
+        self._pending.append((geo, done))
 
     def get(self):
-        """geometry of the submitted batch; the current stream waits for it (no host sync)"""
-        geo, done = self._pending
-        self._pending = None
+        """geometry of the oldest submitted batch; the current stream waits for it (no host sync)"""
+        geo, done = self._pending.pop(0)
         main = torch.cuda.current_stream()
         main.wait_event(done)
         _walk(geo, lambda t: t.record_stream(main))  # allocated on the side stream, consumed on main

@@ -617,6 +617,16 @@ def test_stack_with_prefetched_geometry_matches_inline(hf):
     assert torch.equal(out_inline, out_pre)
     out_pre.mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    # two batches in flight, one HIP stream each: results come back in submission order and match inline
+    xyz_b = dev(kitti_uniform(rng, 2, 2048))
+    pf2 = GeometryPrefetcher(net.geometry, depth=2)
+    pf2.submit(xyz); pf2.submit(xyz_b)
+    assert len(pf2) == 2
+    with torch.no_grad():
+        for pts in (xyz, xyz_b, xyz):
+            geo = pf2.get()
+            pf2.submit(pts)
+            assert torch.equal(net(pts, inten, geometry=geo), net(pts, inten))
 
 
 def test_sa_module_composition_against_oracle(hf, oracle_mod):
