@@ -138,6 +138,109 @@ __global__ void three_interpolate_cl_grad_kernel(int m, int c, long long n_per_b
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Inverse of a three_nn index (CSR over the known points) and the gather form of the interpolation gradient.
+// The scatter form above issues 3*N*C float atomics; with the inverse each known point sums its referencing
+// rows in registers and writes once, in ascending (unknown point, slot) order -- the accumulation order of the
+// sequential loop in tf_interpolate.cpp:150-167, so the result is deterministic and matches it bit for bit.
+// One 1024-thread workgroup per cloud: counts and cursors live in LDS (2*m ints).
+// ------------------------------------------------------------------------------------------
+constexpr int kInvThreads = 1024;
+constexpr int kInvMaxKnown = 8192;
+
+__global__ __launch_bounds__(kInvThreads) void three_nn_inverse_kernel(int n, int m, const int *__restrict__ idx,
+                                                                       int *__restrict__ offsets,
+                                                                       int *__restrict__ entries)
+{
+    extern __shared__ int inv_lds[];
+    __shared__ int wsum[16];
+    int *cnt = inv_lds, *cur = inv_lds + m;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const long long total = 3ll * n;
+    const int *ib = idx + b * total;
+    int *off = offsets + static_cast<long long>(b) * (m + 1);
+    int *ent = entries + b * total;
+    for (int i = t; i < m; i += kInvThreads) cnt[i] = 0;
+    __syncthreads();
+    for (long long e = t; e < total; e += kInvThreads) {
+        const int k = ib[e];
+        if (k >= 0 && k < m) atomicAdd(&cnt[k], 1);
+    }
+    __syncthreads();
+    int carry = 0;
+    for (int base = 0; base < m; base += kInvThreads) {
+        const int i = base + t;
+        const int v = i < m ? cnt[i] : 0;
+        int tot;
+        const int ex = block_exclusive_scan(v, wsum, &tot);
+        if (i < m) {
+            cur[i] = carry + ex;
+            off[i] = carry + ex;
+        }
+        carry += tot;
+    }
+    if (t == 0) off[m] = carry;
+    __syncthreads();
+    for (long long e = t; e < total; e += kInvThreads) {
+        const int k = ib[e];
+        if (k >= 0 && k < m) ent[atomicAdd(&cur[k], 1)] = static_cast<int>(e);
+    }
+    __syncthreads();  // bucket contents (global memory) visible to the whole workgroup
+    // ascending order inside every bucket: insertion sort, buckets hold ~3n/m entries
+    for (int i = t; i < m; i += kInvThreads) {
+        const int lo = cur[i] - cnt[i], hi = cur[i];
+        for (int a = lo + 1; a < hi; ++a) {
+            const int v = ent[a];
+            int p = a - 1;
+            while (p >= lo && ent[p] > v) {
+                ent[p + 1] = ent[p];
+                --p;
+            }
+            ent[p + 1] = v;
+        }
+    }
+}
+
+template <int VEC>
+__global__ void three_interpolate_cl_grad_gather_kernel(int n, int m, int c, int cv, long long known_rows,
+                                                        const float *__restrict__ grad_out,
+                                                        const float *__restrict__ weight,
+                                                        const int *__restrict__ offsets,
+                                                        const int *__restrict__ entries,
+                                                        float *__restrict__ grad_points)
+{
+    const int rows_per_block = blockDim.x / cv;
+    const int cvec = threadIdx.x % cv, rsub = threadIdx.x / cv;
+    if (rsub >= rows_per_block) return;
+    for (long long row = blockIdx.x * static_cast<long long>(rows_per_block) + rsub; row < known_rows;
+         row += static_cast<long long>(gridDim.x) * rows_per_block) {
+        const long long bb = row / m;
+        const int k = static_cast<int>(row - bb * m);
+        const int *off = offsets + bb * (m + 1);
+        const int *ent = entries + bb * 3ll * n;
+        const float *go = grad_out + bb * n * c + cvec * VEC;
+        const float *w = weight + bb * 3ll * n;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        const int lo = off[k], hi = off[k + 1];
+        for (int a = lo; a < hi; ++a) {
+            const int e = ent[a];
+            const float wt = w[e];
+            const float *src = go + static_cast<long long>(e / 3) * c;
+            if constexpr (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(src);
+                acc[0] += v.x * wt; acc[1] += v.y * wt; acc[2] += v.z * wt; acc[3] += v.w * wt;
+            } else {
+                acc[0] += src[0] * wt;
+            }
+        }
+        float *dst = grad_points + row * c + cvec * VEC;
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else dst[0] = acc[0];
+    }
+}
+
 static int grid_for(long long work_items, int block)
 {
     long long g = (work_items + block - 1) / block;
@@ -220,5 +323,40 @@ HF_API int hf_three_interpolate_cl_grad(int b, int n, int c, int m, const float 
     const int block = 256;
     hipLaunchKernelGGL(three_interpolate_cl_grad_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, m, c,
                        static_cast<long long>(n), nrows, grad_out, idx, weight, grad_points);
+    return launch_status();
+}
+
+HF_API int hf_three_nn_inverse(int b, int n, int m, const int *idx, int *offsets, int *entries, hf_stream_t stream)
+{
+    if (b < 0 || n < 0 || m <= 0 || m > kInvMaxKnown || !offsets || (n > 0 && (!idx || !entries))) return HF_EINVAL;
+    if (b == 0) return HF_OK;
+    if (static_cast<long long>(n) * 3 > 0x7fffffffll) return HF_EINVAL;
+    hipLaunchKernelGGL(three_nn_inverse_kernel, dim3(b), dim3(kInvThreads), sizeof(int) * 2 * static_cast<size_t>(m),
+                       as_stream(stream), n, m, idx, offsets, entries);
+    return launch_status();
+}
+
+HF_API int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const float *grad_out, const float *weight,
+                                               const int *offsets, const int *entries, float *grad_points,
+                                               hf_stream_t stream)
+{
+    if (b < 0 || n < 0 || c < 0 || m <= 0 || !offsets || !grad_points || (n > 0 && c > 0 && (!grad_out || !weight || !entries)))
+        return HF_EINVAL;
+    const long long known_rows = static_cast<long long>(b) * m;
+    if (known_rows == 0 || c == 0) return HF_OK;
+    const bool vec4 = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_points)) % 16 == 0);
+    const int cv = vec4 ? c / 4 : c;
+    if (cv > 1024) return HF_EINVAL;
+    int block = 256;
+    if (cv > block) block = ((cv + 63) / 64) * 64;
+    const int rows_per_block = block / cv;
+    long long grid = (known_rows + rows_per_block - 1) / rows_per_block;
+    if (grid > kNumCU * 64ll) grid = kNumCU * 64ll;
+    if (vec4)
+        hipLaunchKernelGGL((three_interpolate_cl_grad_gather_kernel<4>), dim3(static_cast<unsigned>(grid)), dim3(block), 0,
+                           as_stream(stream), n, m, c, cv, known_rows, grad_out, weight, offsets, entries, grad_points);
+    else
+        hipLaunchKernelGGL((three_interpolate_cl_grad_gather_kernel<1>), dim3(static_cast<unsigned>(grid)), dim3(block), 0,
+                           as_stream(stream), n, m, c, cv, known_rows, grad_out, weight, offsets, entries, grad_points);
     return launch_status();
 }

@@ -22,6 +22,49 @@ def three_nn(xyz1, xyz2):
     return dist, idx
 
 
+INVERSE_MAX_KNOWN = 8192
+
+
+def three_nn_inverse(idx, m):
+    """idx (B,N,3) int32 from three_nn over M known points -> (offsets (B,M+1), entries (B,3N)) int32: for every
+    known point the flat (unknown*3 + slot) positions that reference it, ascending.  Coordinates-only, like
+    three_nn itself, so it can be prepared ahead of the features (pipeline.GeometryPrefetcher)."""
+    idx = dev_tensor(idx, torch.int32, "idx")
+    require(idx.dim() == 3 and idx.shape[2] == 3, "three_nn_inverse expects (b,n,3) idx shape")
+    require(0 < m <= INVERSE_MAX_KNOWN, "three_nn_inverse expects 0 < m <= %d" % INVERSE_MAX_KNOWN)
+    b, n, _ = idx.shape
+    offsets = torch.empty((b, m + 1), dtype=torch.int32, device=idx.device)
+    entries = torch.empty((b, 3 * n), dtype=torch.int32, device=idx.device)
+    check(_lib.lib().hf_three_nn_inverse(b, n, m, ptr(idx), ptr(offsets), ptr(entries), stream_ptr()), "three_nn_inverse")
+    return offsets, entries
+
+
+class _ThreeInterpolateInv(torch.autograd.Function):
+    """three_interpolate whose gradient gathers over a prepared inverse index instead of scattering atomics"""
+
+    @staticmethod
+    def forward(ctx, points, idx, weight, offsets, entries):
+        b, m, c = points.shape
+        n = idx.shape[1]
+        out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
+        check(_lib.lib().hf_three_interpolate_cl(b, m, c, n, ptr(points), ptr(idx), ptr(weight), ptr(out),
+                                                 stream_ptr()), "three_interpolate")
+        ctx.save_for_backward(weight, offsets, entries)
+        ctx.shape = (b, m, c, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        weight, offsets, entries = ctx.saved_tensors
+        b, m, c, n = ctx.shape
+        grad_out = grad_out.contiguous()
+        g = torch.empty((b, m, c), dtype=torch.float32, device=grad_out.device)
+        check(_lib.lib().hf_three_interpolate_cl_grad_gather(b, n, c, m, ptr(grad_out), ptr(weight), ptr(offsets),
+                                                             ptr(entries), ptr(g), stream_ptr()),
+              "three_interpolate_grad_gather")
+        return g, None, None, None, None
+
+
 class _ThreeInterpolate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx, weight):
@@ -46,8 +89,9 @@ class _ThreeInterpolate(torch.autograd.Function):
         return g, None, None
 
 
-def three_interpolate(points, idx, weight):
+def three_interpolate(points, idx, weight, inverse=None):
     """points (B,M,C), idx (B,N,3) int32, weight (B,N,3) -> (B,N,C).
+    `inverse` = three_nn_inverse(idx, M) (optional): the gradient then gathers instead of using atomics.
     Reference: tf_interpolate.py:26-49 -- it transposes to (B,C,M), runs the channel-first op and
     transposes back; the channel-last kernel gives the same values without the two transposes.
     Gradient w.r.t. points only (idx, weight get None, :44-48)."""
@@ -58,6 +102,12 @@ def three_interpolate(points, idx, weight):
     points = dev_tensor(points, torch.float32, "points")
     idx = dev_tensor(idx, torch.int32, "idx")
     weight = dev_tensor(weight.detach(), torch.float32, "weight")
+    if inverse is not None:
+        offsets, entries = inverse
+        require(offsets.shape == (points.shape[0], points.shape[1] + 1) and entries.shape == (idx.shape[0], 3 * idx.shape[1]),
+                "ThreeInterpolate expects the inverse of this idx: offsets (b,m+1), entries (b,3n)")
+        return _ThreeInterpolateInv.apply(points, idx, weight, dev_tensor(offsets, torch.int32, "offsets"),
+                                          dev_tensor(entries, torch.int32, "entries"))
     return _ThreeInterpolate.apply(points, idx, weight)
 
 

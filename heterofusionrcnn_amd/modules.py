@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from .grouping import group_point, knn_point, query_ball_group, query_ball_point
-from .interpolate import three_interpolate, three_nn
+from .interpolate import INVERSE_MAX_KNOWN, three_interpolate, three_nn, three_nn_inverse
 from .sampling import farthest_point_sample, gather_point
 from .mlp import BatchNormReLU, linear_bn_relu, linear_bn_relu_maxpool
 from .bev_iou import compute_bev_iou as _compute_bev_iou, oriented_nms as _oriented_nms
@@ -256,11 +256,13 @@ class PointnetFPModule(nn.Module):
         """three_nn + inverse-distance weights: coordinates only"""
         with torch.no_grad():
             dist, idx = three_nn(xyz1, xyz2)
-            return idx, three_nn_weights(dist)
+            m = xyz2.shape[1]
+            inverse = three_nn_inverse(idx, m) if m <= INVERSE_MAX_KNOWN else None
+            return idx, three_nn_weights(dist), inverse
 
     def forward(self, xyz1, xyz2, points1, points2, geom=None):
-        idx, weight = geom if geom is not None else self.geometry(xyz1, xyz2)
-        interpolated = three_interpolate(points2, idx, weight)
+        idx, weight, inverse = geom if geom is not None else self.geometry(xyz1, xyz2)
+        interpolated = three_interpolate(points2, idx, weight, inverse if torch.is_grad_enabled() else None)
         new_points = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
         return self.mlp(new_points)
 
@@ -292,7 +294,7 @@ class PointnetSAFPStack(nn.Module):
 
     def geometry(self, xyz):
         """Every sampling / grouping / neighbour result of one pass: a function of xyz alone.
-        Returns {"sa": [(new_xyz, idx, grouped_xyz) per level], "fp": [(idx3, weight) per level, deepest first]}."""
+        Returns {"sa": [(new_xyz, idx, grouped_xyz) per level], "fp": [(idx3, weight, inverse index) per level, deepest first]}."""
         sa, xyzs = [], [xyz]
         for m in self.sa:
             g = m.geometry(xyzs[-1])

@@ -196,6 +196,16 @@ int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const
                    const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                    float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* Inverse of a three_nn index (tf_interpolate.cpp:68-75 produces idx): for every known point the (unknown point,
+ * slot) pairs that reference it, as CSR.  offsets (b, m+1) int32, entries (b, 3n) int32 holding unknown*3+slot in
+ * ascending order inside each bucket; idx values outside [0, m) are dropped.  m <= 8192. */
+int hf_three_nn_inverse(int b, int n, int m, const int *idx, int *offsets, int *entries, hf_stream_t stream);
+/* ThreeInterpolateGrad (tf_interpolate.cpp:39-48, 150-167) in gather form over that inverse, channel-last:
+ * grad_out (b,n,c), weight (b,n,3) -> grad_points (b,m,c).  No atomics; sums in the order of the reference's
+ * sequential loop (ascending unknown point, then slot). */
+int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const float *grad_out, const float *weight,
+                                        const int *offsets, const int *entries, float *grad_points, hf_stream_t stream);
+
 /* BN + ReLU + max over the k rows of every group, fused: the tail of a set-abstraction MLP
  * (tf_util.conv2d(..., bn=True) then tf.reduce_max(axis=[2]), pointnet_util.py:156-176).  z is (groups*k, c)
  * pre-BN; pooled is (groups, c).  training != 0: batch statistics are computed here (and the running estimates

@@ -282,6 +282,42 @@ def test_oracle_three_nn(hf, oracle_mod, b, n, m):
     assert np.array_equal(host(dist), od)
 
 
+@pytest.mark.parametrize("b,n,m,c", [(2, 400, 90, 16), (1, 1, 1, 4), (3, 5000, 7, 30), (2, 16384, 4096, 128), (1, 300, 8192, 1)])
+def test_three_nn_inverse_and_gather_gradient(hf, oracle_mod, b, n, m, c):
+    """CSR inverse of a three_nn index and the gather form of ThreeInterpolateGrad: buckets hold ascending
+    (unknown*3+slot) positions, so the sum order is the reference's sequential loop -> bit-exact with the oracle"""
+    from heterofusionrcnn_amd.interpolate import three_nn_inverse
+    rng = np.random.default_rng(n + m)
+    idx3 = rng.integers(0, m, (b, n, 3)).astype(np.int32)
+    if n > 100:
+        idx3[0, : n // 2, 1] = m // 2          # one heavily referenced known point
+    w = rng.random((b, n, 3), dtype=np.float32)
+    off, ent = three_nn_inverse(dev(idx3), m)
+    off, ent = host(off), host(ent)
+    for i in range(b):
+        flat = idx3[i].reshape(-1)
+        order = np.argsort(flat, kind="stable")
+        assert np.array_equal(off[i], np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=m))]))
+        assert np.array_equal(ent[i], order)
+    pts = rng.standard_normal((b, m, c)).astype(np.float32)
+    go = rng.standard_normal((b, n, c)).astype(np.float32)
+    p = dev(pts).requires_grad_(True)
+    out = hf.three_interpolate(p, dev(idx3), dev(w), inverse=three_nn_inverse(dev(idx3), m))
+    assert np.array_equal(host(out), oracle_mod.three_interpolate(pts, idx3, w))
+    out.backward(dev(go))
+    assert np.array_equal(host(p.grad), oracle_mod.three_interpolate_grad(pts.shape, idx3, w, go))
+
+
+def test_three_nn_inverse_drops_out_of_range(hf):
+    from heterofusionrcnn_amd.interpolate import three_nn_inverse
+    idx3 = np.array([[[0, 5, 1], [-1, 1, 2], [1, 1, 99]]], np.int32)
+    off, ent = three_nn_inverse(dev(idx3), 3)
+    assert host(off).tolist() == [[0, 1, 5, 6]]
+    assert host(ent)[0, :6].tolist() == [0, 2, 4, 6, 7, 5]
+    with pytest.raises(ValueError):
+        three_nn_inverse(dev(idx3), 8193)
+
+
 @pytest.mark.parametrize("c", [1, 3, 16, 30, 256])
 def test_oracle_interpolate_group_channels(hf, oracle_mod, c):
     rng = np.random.default_rng(c)
