@@ -47,6 +47,8 @@ _SIGNATURES = {
     "hf_bn_relu_fwd_train": [ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_bn_relu_fwd_eval": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "hf_bn_relu_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_three_nn_workspace": [_i, _i],
+    "hf_three_nn_sorted": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_three_nn_inverse": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_three_interpolate_cl_grad_gather": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_bn_relu_maxpool_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -61,6 +63,7 @@ _RESTYPES = {
     "hf_fps_workspace": _sz,
     "hf_oriented_nms_workspace": _sz,
     "hf_bn_workspace": _sz,
+    "hf_three_nn_workspace": _sz,
     "hf_version": ctypes.c_char_p,
     "hf_strerror": ctypes.c_char_p,
 }

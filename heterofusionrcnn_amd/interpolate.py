@@ -18,6 +18,25 @@ def three_nn(xyz1, xyz2):
     m = xyz2.shape[1]
     dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
+    L = _lib.lib()
+    nbytes = L.hf_three_nn_workspace(b, m)
+    if nbytes:  # sorted-sweep kernels; larger clouds take the all-pairs kernel
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=xyz1.device)
+        check(L.hf_three_nn_sorted(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), ptr(ws), nbytes, stream_ptr()),
+              "three_nn")
+    else:
+        check(L.hf_three_nn(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), stream_ptr()), "three_nn")
+    return dist, idx
+
+
+def three_nn_all_pairs(xyz1, xyz2):
+    """the reference's O(n*m) scan (ThreeNNGpuOp as written), kept as its own entry point"""
+    xyz1 = dev_tensor(xyz1.detach(), torch.float32, "xyz1")
+    xyz2 = dev_tensor(xyz2.detach(), torch.float32, "xyz2")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
     check(_lib.lib().hf_three_nn(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), stream_ptr()), "three_nn")
     return dist, idx
 

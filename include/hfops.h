@@ -196,6 +196,14 @@ int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const
                    const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                    float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* three_nn (tf_interpolate.cpp:68-75) with a scratch buffer: the known points of every cloud are sorted along x
+ * first, each query then sweeps outwards from its own x and stops as soon as (dx)^2 exceeds its third-best
+ * distance.  Same outputs as hf_three_nn, bit for bit (ties to the lower index).  hf_three_nn_workspace returns
+ * 0 when m is too large for the sorted cloud to sit in LDS; hf_three_nn_sorted then runs hf_three_nn. */
+size_t hf_three_nn_workspace(int b, int m);
+int hf_three_nn_sorted(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                       void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 /* Inverse of a three_nn index (tf_interpolate.cpp:68-75 produces idx): for every known point the (unknown point,
  * slot) pairs that reference it, as CSR.  offsets (b, m+1) int32, entries (b, 3n) int32 holding unknown*3+slot in
  * ascending order inside each bucket; idx values outside [0, m) are dropped.  m <= 8192. */

@@ -9,12 +9,12 @@ from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
 from bench import kitti_uniform, B, N0, SA, FP
 torch.manual_seed(0)
 model = modules.PointnetSAFPStack(in_channel=1, sa=SA, fp=FP).cuda()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 rng = np.random.default_rng(0)
 xyz = torch.from_numpy(kitti_uniform(rng, B, N0)).cuda()
 inten = torch.from_numpy(rng.uniform(-.5, .5, (B, N0, 1)).astype(np.float32)).cuda()
-pf = GeometryPrefetcher(model.geometry)
-pf.submit(xyz)
+pf = GeometryPrefetcher(model.geometry, depth=2)
+pf.submit(xyz); pf.submit(xyz)
 def step():
     geo = pf.get(); pf.submit(xyz)
     opt.zero_grad(set_to_none=True)
@@ -22,7 +22,7 @@ def step():
     loss.backward(); opt.step()
 for _ in range(3): step()
 torch.cuda.synchronize()
-K = 10
+K = 20
 t0 = time.perf_counter()
 for _ in range(K): step()
 t_enq = time.perf_counter() - t0

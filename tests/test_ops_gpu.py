@@ -282,6 +282,44 @@ def test_oracle_three_nn(hf, oracle_mod, b, n, m):
     assert np.array_equal(host(dist), od)
 
 
+@pytest.mark.parametrize("kind", ["lattice", "same_x", "clustered", "two_known", "nonfinite", "max_lds", "beyond_lds"])
+def test_three_nn_sorted_sweep_matches_all_pairs_scan(hf, oracle_mod, kind):
+    """hf.three_nn sorts the known points along x and sweeps outwards; it must give the all-pairs scan's answer
+    bit for bit (distances, and ties to the lower index) on inputs built to stress the sweep's stop rule"""
+    from heterofusionrcnn_amd.interpolate import three_nn_all_pairs
+    rng = np.random.default_rng(len(kind))
+    b, n, m = 2, 3000, 700
+    if kind == "lattice":        # integer lattice: masses of exactly equal distances and equal x
+        k = rng.integers(0, 6, (b, m, 3)).astype(np.float32)
+        u = (rng.integers(0, 6, (b, n, 3)) + 0.5 * rng.integers(0, 2, (b, n, 3))).astype(np.float32)
+    elif kind == "same_x":       # no pruning possible along x
+        k = kitti_uniform(rng, b, m); k[..., 0] = 3.25
+        u = kitti_uniform(rng, b, n)
+    elif kind == "clustered":
+        k = (rng.standard_normal((b, m, 3)) * 0.05).astype(np.float32) + np.float32(10)
+        k[:, ::7] += 30
+        u = kitti_uniform(rng, b, n); u[:, ::2] = (k[:, rng.integers(0, m, n // 2)] + np.float32(1e-3)).astype(np.float32)
+    elif kind == "two_known":
+        m = 2
+        k = kitti_uniform(rng, b, m); u = kitti_uniform(rng, b, n)
+    elif kind == "nonfinite":    # NaN / inf coordinates never win a `<` in the reference either
+        k = kitti_uniform(rng, b, m); u = kitti_uniform(rng, b, n)
+        k[0, 5, 0] = np.nan; k[0, 9, 1] = np.inf; k[1, 3, 0] = -np.inf; u[0, 7, 0] = np.nan; u[1, 8, 2] = np.inf
+    elif kind == "max_lds":
+        b, n, m = 1, 2000, 8192
+        k = kitti_uniform(rng, b, m); u = kitti_uniform(rng, b, n)
+    else:                        # one more known point than the sweep handles: the all-pairs kernel answers
+        b, n, m = 1, 500, 8193
+        k = kitti_uniform(rng, b, m); u = kitti_uniform(rng, b, n)
+    dist, idx = hf.three_nn(dev(u), dev(k))
+    d2, i2 = three_nn_all_pairs(dev(u), dev(k))
+    assert torch.equal(idx, i2)
+    assert np.array_equal(host(dist), host(d2), equal_nan=True)
+    if kind != "nonfinite":
+        od, oi = oracle_mod.three_nn(u, k)
+        assert np.array_equal(host(idx), oi) and np.array_equal(host(dist), od)
+
+
 @pytest.mark.parametrize("b,n,m,c", [(2, 400, 90, 16), (1, 1, 1, 4), (3, 5000, 7, 30), (2, 16384, 4096, 128), (1, 300, 8192, 1)])
 def test_three_nn_inverse_and_gather_gradient(hf, oracle_mod, b, n, m, c):
     """CSR inverse of a three_nn index and the gather form of ThreeInterpolateGrad: buckets hold ascending
