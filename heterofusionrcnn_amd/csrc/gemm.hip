@@ -1,0 +1,243 @@
+// gemm.hip -- fp32 MFMA GEMMs of the shared-MLP layers for gfx950.
+//
+// Caller side of the hot path: tf_util.conv2d([1,1]) on R = B*M*K grouped rows
+// (hf/core/feature_extractors/tf_util.py:180-203) is a tall-skinny GEMM, R ~ 1e4..1e6 rows against 4..384
+// channels, and so are its two gradients.  All three are built on v_mfma_f32_32x32x2_f32: f32 in, f32
+// accumulate, bit-for-bit a k-ordered fmaf chain, so the arithmetic type of the path stays fp32.
+//
+// Lane maps of the 32x32x2 form (lane l): A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+// D register g holds row i = 8*(g>>2) + 4*(l>>5) + (g&3), column j = l&31.
+//
+//   wgrad   dW (Cout, Cin) = G^T X, the reduction runs over rows.  Both operands are read in their row-major
+//           global layout and staged in LDS as they are: lane (l&31) walks channels, (l>>5) picks the row of a
+//           pair, so LDS reads are conflict-free and no transpose exists anywhere.  Rows are cut into chunks,
+//           one workgroup per (output tile, chunk); partial tiles are summed in a fixed order by a second
+//           kernel (deterministic, no atomics).  X may be given as the previous layer's pre-BN output: the
+//           BN affine + ReLU is then applied while staging ("activation on load").
+#include <math.h>
+#include <stdint.h>
+
+#include "hf_common.h"
+
+namespace hf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGemmThreads = 256;
+constexpr int kGemmRowsPerStage = 32;  // rows staged in LDS per step = 16 MFMA k-pairs
+
+// four consecutive floats of row `row`, zero outside [0, row_end) x [0, ncols)
+__device__ __forceinline__ float4 load4_guarded(const float *__restrict__ base, long long row, long long row_end,
+                                                int col, int ncols, bool vec)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < row_end && col < ncols) {
+        const float *p = base + row * ncols + col;
+        if (vec && col + 3 < ncols) {
+            v = *reinterpret_cast<const float4 *>(p);
+        } else {
+            v.x = p[0];
+            if (col + 1 < ncols) v.y = p[1];
+            if (col + 2 < ncols) v.z = p[2];
+            if (col + 3 < ncols) v.w = p[3];
+        }
+    }
+    return v;
+}
+
+// per-thread BN affine + ReLU of the four columns a thread stages: y = max(a*x + c, 0)
+struct ColAct {
+    float a[4], c[4];
+    bool on;
+};
+
+__device__ __forceinline__ ColAct make_col_act(int col, int ncols, const float *gamma, const float *beta,
+                                               const float *mean, const float *invstd)
+{
+    ColAct f;
+    f.on = gamma != nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f.a[i] = 1.f;
+        f.c[i] = 0.f;
+        if (f.on && col + i < ncols) {
+            f.a[i] = gamma[col + i] * invstd[col + i];
+            f.c[i] = beta[col + i] - mean[col + i] * f.a[i];
+        }
+    }
+    return f;
+}
+
+__device__ __forceinline__ float4 apply_col_act(const ColAct &f, float4 v, bool inside)
+{
+    if (f.on && inside) {  // rows / columns outside the matrix must stay zero
+        v.x = fmaxf(f.a[0] * v.x + f.c[0], 0.f);
+        v.y = fmaxf(f.a[1] * v.y + f.c[1], 0.f);
+        v.z = fmaxf(f.a[2] * v.z + f.c[2], 0.f);
+        v.w = fmaxf(f.a[3] * v.w + f.c[3], 0.f);
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: partial[chunk][n][k] = sum over the chunk's rows of G[r][n] * act(X)[r][k]
+// WM / WN: 32x32 MFMA tiles per wave along Cout / Cin; a workgroup is 2 x 2 waves -> tile 64*WM x 64*WN.
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(kGemmThreads) void wgrad_kernel(long long rows, int cout, int cin, int mtiles,
+                                                             long long rows_per_chunk, const float *__restrict__ G,
+                                                             const float *__restrict__ X, int gvec, int xvec,
+                                                             const float *__restrict__ in_gamma,
+                                                             const float *__restrict__ in_beta,
+                                                             const float *__restrict__ in_mean,
+                                                             const float *__restrict__ in_invstd,
+                                                             float *__restrict__ partial)
+{
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int GS = TM + 32, XS = TN + 32;  // LDS row strides: the two row-halves of a wave land on disjoint banks
+    constexpr int GC4 = TM / 4, XC4 = TN / 4;  // float4 per staged row
+    constexpr int GPASS = kGemmRowsPerStage * GC4 / kGemmThreads, XPASS = kGemmRowsPerStage * XC4 / kGemmThreads;
+    constexpr int GROWS = kGemmThreads / GC4, XROWS = kGemmThreads / XC4;  // rows covered per pass
+    __shared__ float Gs[kGemmRowsPerStage * GS];
+    __shared__ float Xs[kGemmRowsPerStage * XS];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile_m = blockIdx.x % mtiles, tile_n = blockIdx.x / mtiles;
+    const long long r0 = blockIdx.y * rows_per_chunk;
+    const long long r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+
+    const int gcol = tile_m * TM + (t % GC4) * 4, grow = t / GC4;
+    const int xcol = tile_n * TN + (t % XC4) * 4, xrow = t / XC4;
+    const ColAct act = make_col_act(xcol, cin, in_gamma, in_beta, in_mean, in_invstd);
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+    float4 gr[GPASS], xr[XPASS];
+    auto fetch = [&](long long rt) {
+#pragma unroll
+        for (int p = 0; p < GPASS; ++p) gr[p] = load4_guarded(G, rt + grow + p * GROWS, r1, gcol, cout, gvec);
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const long long r = rt + xrow + p * XROWS;
+            xr[p] = apply_col_act(act, load4_guarded(X, r, r1, xcol, cin, xvec), r < r1);
+        }
+    };
+    fetch(r0);
+    for (long long rt = r0; rt < r1; rt += kGemmRowsPerStage) {
+#pragma unroll
+        for (int p = 0; p < GPASS; ++p)
+            *reinterpret_cast<float4 *>(&Gs[(grow + p * GROWS) * GS + (t % GC4) * 4]) = gr[p];
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p)
+            *reinterpret_cast<float4 *>(&Xs[(xrow + p * XROWS) * XS + (t % XC4) * 4]) = xr[p];
+        __syncthreads();
+        if (rt + kGemmRowsPerStage < r1) fetch(rt + kGemmRowsPerStage);  // in flight during the MFMAs below
+        const float *ga = Gs + (lane >> 5) * GS + wm * 32 * WM + (lane & 31);
+        const float *xb = Xs + (lane >> 5) * XS + wn * 32 * WN + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < kGemmRowsPerStage / 2; ++s) {
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = ga[2 * s * GS + i * 32];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = xb[2 * s * XS + j * 32];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float *out = partial + static_cast<size_t>(blockIdx.y) * cout * cin;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int k = tile_n * TN + wn * 32 * WN + j * 32 + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int n = tile_m * TM + wm * 32 * WM + i * 32 + 8 * (g >> 2) + 4 * (lane >> 5) + (g & 3);
+                if (n < cout && k < cin) out[static_cast<size_t>(n) * cin + k] = acc[i][j][g];
+            }
+        }
+}
+
+// dW[e] = sum over chunks, ascending: one thread per element
+__global__ void wgrad_reduce_kernel(int total, int chunks, const float *__restrict__ partial, float *__restrict__ dw)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[static_cast<size_t>(c) * total + e];
+    dw[e] = s;
+}
+
+struct WgradPlan {
+    int wm, wn, mtiles, ntiles, chunks;
+    long long rows_per_chunk;
+};
+
+static WgradPlan wgrad_plan(long long rows, int cout, int cin)
+{
+    WgradPlan p;
+    p.wm = cout > 64 ? 2 : 1;
+    p.wn = cin > 64 ? 2 : 1;
+    p.mtiles = div_up(cout, 64 * p.wm);
+    p.ntiles = div_up(cin, 64 * p.wn);
+    // ~4 workgroups per CU in total; a chunk is at least 256 rows and a multiple of the 32-row stage
+    long long want = static_cast<long long>(kNumCU) * 4 / (p.mtiles * p.ntiles);
+    if (want < 1) want = 1;
+    long long rpc = (rows + want - 1) / want;
+    if (rpc < 256) rpc = 256;
+    rpc = (rpc + kGemmRowsPerStage - 1) / kGemmRowsPerStage * kGemmRowsPerStage;
+    p.rows_per_chunk = rpc;
+    p.chunks = static_cast<int>((rows + rpc - 1) / rpc);
+    return p;
+}
+
+static bool vec4_ok(const void *p, int ncols) { return ncols % 4 == 0 && reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+}  // namespace hf
+
+using namespace hf;
+
+HF_API size_t hf_linear_wgrad_workspace(long long rows, int cout, int cin)
+{
+    if (rows <= 0 || cout <= 0 || cin <= 0) return 0;
+    const WgradPlan p = wgrad_plan(rows, cout, cin);
+    return sizeof(float) * static_cast<size_t>(p.chunks) * cout * cin;
+}
+
+HF_API int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_z, const float *x, const float *in_gamma,
+                           const float *in_beta, const float *in_mean, const float *in_invstd, float *grad_weight,
+                           void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows <= 0 || cout <= 0 || cin <= 0 || cout > 4096 || cin > 4096 || !grad_z || !x || !grad_weight) return HF_EINVAL;
+    if (in_gamma && (!in_beta || !in_mean || !in_invstd)) return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_linear_wgrad_workspace(rows, cout, cin)) return HF_EWORKSPACE;
+    const WgradPlan p = wgrad_plan(rows, cout, cin);
+    if (p.chunks > 65535) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const dim3 grid(p.mtiles * p.ntiles, p.chunks);
+    const int gvec = vec4_ok(grad_z, cout), xvec = vec4_ok(x, cin);
+#define HF_WGRAD(M, N)                                                                                                  \
+    hipLaunchKernelGGL((wgrad_kernel<M, N>), grid, dim3(kGemmThreads), 0, st, rows, cout, cin, p.mtiles, p.rows_per_chunk, \
+                       grad_z, x, gvec, xvec, in_gamma, in_beta, in_mean, in_invstd, partial)
+    if (p.wm == 2 && p.wn == 2) HF_WGRAD(2, 2);
+    else if (p.wm == 2) HF_WGRAD(2, 1);
+    else if (p.wn == 2) HF_WGRAD(1, 2);
+    else HF_WGRAD(1, 1);
+#undef HF_WGRAD
+    const int total = cout * cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(total, 256)), dim3(256), 0, st, total, p.chunks, partial, grad_weight);
+    return launch_status();
+}
