@@ -254,6 +254,9 @@ def main():
     ap.add_argument("--no-op-table", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the geometry ops inline instead of one step ahead")
     ap.add_argument("--prefetch-depth", type=int, default=2, help="batches of geometry in flight (one HIP stream each)")
+    ap.add_argument("--prefetch-group", type=int, default=0,
+                    help="batches whose geometry is computed in one launch (0 = the largest divisor of --steps up to 8, "
+                         "so that the timed steps contain exactly as many geometry launches as they consume)")
     ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
 
@@ -281,7 +284,8 @@ def main():
     intensity = torch.from_numpy(rng.uniform(-0.5, 0.5, (B, N0, 1)).astype(np.float32)).cuda()
 
     from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
-    prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth)
+    group = args.prefetch_group or max(g for g in range(1, 9) if args.steps % g == 0)
+    prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth, group=group)
 
     def step():
         # the coordinate-only ops of the NEXT batch run on a side stream while this batch trains;
@@ -298,10 +302,14 @@ def main():
         return loss
 
     if prefetch is not None:
-        for _ in range(prefetch.depth):
+        for _ in range(prefetch.capacity):
             prefetch.submit(xyz)
     for _ in range(args.warmup):
         step()
+    align = 0
+    while prefetch is not None and prefetch.staged:  # start the timed steps on a group boundary: K steps then
+        step()                                       # launch the geometry of exactly K batches
+        align += 1
 
     dp.fence(ctx)
     timer.enabled = True
@@ -328,14 +336,17 @@ def main():
             "config": {"workload": "SA+FP stack 16384->4096->1024->256, K=32, radii 0.5/1.0/2.0, B=8 frames per GPU, "
                                    "fwd+bwd+Adam, fp32 (BASELINE.json configs[1])",
                        "frames_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
-                       "geometry_prefetch_depth": prefetch.depth if prefetch is not None else 0},
+                       "geometry_prefetch_depth": prefetch.depth if prefetch is not None else 0,
+                       "geometry_prefetch_group": prefetch.group if prefetch is not None else 0,
+                       "extra_untimed_alignment_steps": align},
             "roofline": {"kernel": "query_ball_point+group_point fused (hf_query_ball_group_xyz), B=8 N=16384 M=4096 K=32",
                          "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
                          "traffic": measured_traffic(), "algorithmic_bytes": algo, "avg_launch_us": round(k_us, 3) if k_us else None,
                          "launches_timed": n_burst,
                          "in_step_avg_launch_us": round(in_step_us, 3) if in_step_us else None,
-                         "in_step_launches": len(timer.pairs)},
+                         "in_step_launches": len(timer.pairs),
+                         "in_step_clouds_per_launch": B * (prefetch.group if prefetch is not None else 1)},
         }
     if rank == 0 and world == 1:
         if not args.no_op_table:

@@ -26,23 +26,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kGemmThreads = 256;
 constexpr int kGemmRowsPerStage = 32;  // rows staged in LDS per step = 16 MFMA k-pairs
 
-// four consecutive floats of row `row`, zero outside [0, row_end) x [0, ncols)
+// four consecutive floats of row `row`, zero outside [0, row_end) x [0, ncols).  Branch-free: an out-of-range
+// access reads a safe address and is replaced by zero afterwards.  VEC: ncols % 4 == 0 and a 16-byte aligned base.
+template <bool VEC>
 __device__ __forceinline__ float4 load4_guarded(const float *__restrict__ base, long long row, long long row_end,
-                                                int col, int ncols, bool vec)
+                                                int col, int ncols)
 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < row_end && col < ncols) {
-        const float *p = base + row * ncols + col;
-        if (vec && col + 3 < ncols) {
-            v = *reinterpret_cast<const float4 *>(p);
-        } else {
-            v.x = p[0];
-            if (col + 1 < ncols) v.y = p[1];
-            if (col + 2 < ncols) v.z = p[2];
-            if (col + 3 < ncols) v.w = p[3];
-        }
+    const bool row_ok = row < row_end;
+    const float *p = base + (row_ok ? row : 0) * ncols;
+    if constexpr (VEC) {
+        const bool ok = row_ok && col < ncols;
+        const float4 v = *reinterpret_cast<const float4 *>(p + (ok ? col : 0));
+        return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        float4 v;
+        const bool k0 = row_ok && col < ncols, k1 = row_ok && col + 1 < ncols, k2 = row_ok && col + 2 < ncols,
+                   k3 = row_ok && col + 3 < ncols;
+        const float x = p[k0 ? col : 0], y = p[k1 ? col + 1 : 0], z = p[k2 ? col + 2 : 0], w = p[k3 ? col + 3 : 0];
+        v.x = k0 ? x : 0.f; v.y = k1 ? y : 0.f; v.z = k2 ? z : 0.f; v.w = k3 ? w : 0.f;
+        return v;
     }
-    return v;
 }
 
 // per-thread BN affine + ReLU of the four columns a thread stages: y = max(a*x + c, 0)
@@ -83,10 +86,10 @@ __device__ __forceinline__ float4 apply_col_act(const ColAct &f, float4 v, bool 
 // wgrad: partial[chunk][n][k] = sum over the chunk's rows of G[r][n] * act(X)[r][k]
 // WM / WN: 32x32 MFMA tiles per wave along Cout / Cin; a workgroup is 2 x 2 waves -> tile 64*WM x 64*WN.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN>
+template <int WM, int WN, bool VEC>
 __global__ __launch_bounds__(kGemmThreads) void wgrad_kernel(long long rows, int cout, int cin, int mtiles,
                                                              long long rows_per_chunk, const float *__restrict__ G,
-                                                             const float *__restrict__ X, int gvec, int xvec,
+                                                             const float *__restrict__ X,
                                                              const float *__restrict__ in_gamma,
                                                              const float *__restrict__ in_beta,
                                                              const float *__restrict__ in_mean,
@@ -122,36 +125,43 @@ __global__ __launch_bounds__(kGemmThreads) void wgrad_kernel(long long rows, int
     float4 gr[GPASS], xr[XPASS];
     auto fetch = [&](long long rt) {
 #pragma unroll
-        for (int p = 0; p < GPASS; ++p) gr[p] = load4_guarded(G, rt + grow + p * GROWS, r1, gcol, cout, gvec);
+        for (int p = 0; p < GPASS; ++p) gr[p] = load4_guarded<VEC>(G, rt + grow + p * GROWS, r1, gcol, cout);
 #pragma unroll
-        for (int p = 0; p < XPASS; ++p) {
-            const long long r = rt + xrow + p * XROWS;
-            xr[p] = apply_col_act(act, load4_guarded(X, r, r1, xcol, cin, xvec), r < r1);
-        }
+        for (int p = 0; p < XPASS; ++p) xr[p] = load4_guarded<VEC>(X, rt + xrow + p * XROWS, r1, xcol, cin);
     };
     fetch(r0);
     for (long long rt = r0; rt < r1; rt += kGemmRowsPerStage) {
 #pragma unroll
         for (int p = 0; p < GPASS; ++p)
             *reinterpret_cast<float4 *>(&Gs[(grow + p * GROWS) * GS + (t % GC4) * 4]) = gr[p];
+        // the activation is applied here, not at fetch time: the loads stay in flight across the MFMA loop
 #pragma unroll
         for (int p = 0; p < XPASS; ++p)
-            *reinterpret_cast<float4 *>(&Xs[(xrow + p * XROWS) * XS + (t % XC4) * 4]) = xr[p];
+            *reinterpret_cast<float4 *>(&Xs[(xrow + p * XROWS) * XS + (t % XC4) * 4]) =
+                apply_col_act(act, xr[p], rt + xrow + p * XROWS < r1);
         __syncthreads();
         if (rt + kGemmRowsPerStage < r1) fetch(rt + kGemmRowsPerStage);  // in flight during the MFMAs below
         const float *ga = Gs + (lane >> 5) * GS + wm * 32 * WM + (lane & 31);
         const float *xb = Xs + (lane >> 5) * XS + wn * 32 * WN + (lane & 31);
+        float a[2][WM], b[2][WN];  // operands of the next row pair are read while this pair's MFMAs run
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[0][i] = ga[i * 32];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[0][j] = xb[j * 32];
 #pragma unroll
         for (int s = 0; s < kGemmRowsPerStage / 2; ++s) {
-            float a[WM], b[WN];
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < kGemmRowsPerStage / 2) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = ga[2 * s * GS + i * 32];
+                for (int i = 0; i < WM; ++i) a[nxt][i] = ga[2 * (s + 1) * GS + i * 32];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = xb[2 * s * XS + j * 32];
+                for (int j = 0; j < WN; ++j) b[nxt][j] = xb[2 * (s + 1) * XS + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -170,14 +180,36 @@ __global__ __launch_bounds__(kGemmThreads) void wgrad_kernel(long long rows, int
         }
 }
 
-// dW[e] = sum over chunks, ascending: one thread per element
-__global__ void wgrad_reduce_kernel(int total, int chunks, const float *__restrict__ partial, float *__restrict__ dw)
+// dW[e] = sum over chunks in a fixed order: 64 consecutive elements x 16 chunk groups per workgroup
+// (group g sums chunks g, g+16, ... ascending; the 16 group sums are then added ascending)
+constexpr int kWredGroups = 16;
+__global__ __launch_bounds__(64 * kWredGroups) void wgrad_reduce_kernel(int total, int chunks,
+                                                                        const float *__restrict__ partial,
+                                                                        float *__restrict__ dw)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
+    __shared__ float red[kWredGroups][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += partial[static_cast<size_t>(c) * total + e];
-    dw[e] = s;
+    if (e < total) {
+        int c = grp;
+        for (; c + 3 * kWredGroups < chunks; c += 4 * kWredGroups) {  // four independent loads in flight
+            const float v0 = partial[static_cast<size_t>(c) * total + e];
+            const float v1 = partial[static_cast<size_t>(c + kWredGroups) * total + e];
+            const float v2 = partial[static_cast<size_t>(c + 2 * kWredGroups) * total + e];
+            const float v3 = partial[static_cast<size_t>(c + 3 * kWredGroups) * total + e];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < chunks; c += kWredGroups) s += partial[static_cast<size_t>(c) * total + e];
+    }
+    red[grp][el] = s;
+    __syncthreads();
+    if (grp == 0 && e < total) {
+        float r = red[0][el];
+#pragma unroll
+        for (int g = 1; g < kWredGroups; ++g) r += red[g][el];
+        dw[e] = r;
+    }
 }
 
 struct WgradPlan {
@@ -192,8 +224,8 @@ static WgradPlan wgrad_plan(long long rows, int cout, int cin)
     p.wn = cin > 64 ? 2 : 1;
     p.mtiles = div_up(cout, 64 * p.wm);
     p.ntiles = div_up(cin, 64 * p.wn);
-    // ~4 workgroups per CU in total; a chunk is at least 256 rows and a multiple of the 32-row stage
-    long long want = static_cast<long long>(kNumCU) * 4 / (p.mtiles * p.ntiles);
+    // ~3 workgroups per CU in total; a chunk is at least 256 rows and a multiple of the 32-row stage
+    long long want = static_cast<long long>(kNumCU) * 3 / (p.mtiles * p.ntiles);
     if (want < 1) want = 1;
     long long rpc = (rows + want - 1) / want;
     if (rpc < 256) rpc = 256;
@@ -228,16 +260,22 @@ HF_API int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     const dim3 grid(p.mtiles * p.ntiles, p.chunks);
-    const int gvec = vec4_ok(grad_z, cout), xvec = vec4_ok(x, cin);
-#define HF_WGRAD(M, N)                                                                                                  \
-    hipLaunchKernelGGL((wgrad_kernel<M, N>), grid, dim3(kGemmThreads), 0, st, rows, cout, cin, p.mtiles, p.rows_per_chunk, \
-                       grad_z, x, gvec, xvec, in_gamma, in_beta, in_mean, in_invstd, partial)
-    if (p.wm == 2 && p.wn == 2) HF_WGRAD(2, 2);
-    else if (p.wm == 2) HF_WGRAD(2, 1);
-    else if (p.wn == 2) HF_WGRAD(1, 2);
-    else HF_WGRAD(1, 1);
+    const bool vec = vec4_ok(grad_z, cout) && vec4_ok(x, cin);
+#define HF_WGRAD(M, N, V)                                                                                               \
+    hipLaunchKernelGGL((wgrad_kernel<M, N, V>), grid, dim3(kGemmThreads), 0, st, rows, cout, cin, p.mtiles,              \
+                       p.rows_per_chunk, grad_z, x, in_gamma, in_beta, in_mean, in_invstd, partial)
+#define HF_WGRAD_V(M, N)                                                                                                \
+    do {                                                                                                                \
+        if (vec) HF_WGRAD(M, N, true); else HF_WGRAD(M, N, false);                                                      \
+    } while (0)
+    if (p.wm == 2 && p.wn == 2) HF_WGRAD_V(2, 2);
+    else if (p.wm == 2) HF_WGRAD_V(2, 1);
+    else if (p.wn == 2) HF_WGRAD_V(1, 2);
+    else HF_WGRAD_V(1, 1);
+#undef HF_WGRAD_V
 #undef HF_WGRAD
     const int total = cout * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(total, 256)), dim3(256), 0, st, total, p.chunks, partial, grad_weight);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(total, 64)), dim3(64 * kWredGroups), 0, st, total, p.chunks, partial,
+                       grad_weight);
     return launch_status();
 }

@@ -62,6 +62,22 @@ def _splitk_wgrad(g, x, chunk=None):
     return gw
 
 
+def linear_wgrad(grad_z, x, in_bn=None):
+    """dW (Cout, Cin) = grad_z^T x on the fp32 MFMA kernel (csrc/gemm.hip): rows cut into chunks, partial tiles
+    summed in a fixed order.  in_bn = (gamma, beta, mean, invstd) of the previous layer: x is then that layer's
+    pre-BN output and relu(bn(x)) is applied while it is staged."""
+    rows, cout = grad_z.shape
+    cin = x.shape[1]
+    L = _lib.lib()
+    nbytes = L.hf_linear_wgrad_workspace(rows, cout, cin)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+    g, b, m, i = in_bn if in_bn is not None else (None, None, None, None)
+    check(L.hf_linear_wgrad(rows, cout, cin, ptr(grad_z), ptr(x), ptr(g), ptr(b), ptr(m), ptr(i), ptr(dw), ptr(ws), nbytes,
+                            stream_ptr()), "linear_wgrad")
+    return dw
+
+
 class _LinearBNReLU(torch.autograd.Function):
     """One autograd node for tf_util.conv2d([1,1], bn=True): z = x W^T + b; y = relu(bn(z)).
     Saves x and z only (y is never needed again); the BN backward pass also returns the column sums of dz,

@@ -230,6 +230,15 @@ int hf_bn_relu_maxpool_bwd(long long groups, int k, int c, const float *z, const
                            const float *save_invstd, float *dz, float *dgamma, float *dbeta, float *dz_colsum,
                            void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* Weight gradient of tf_util.conv2d([1,1]) (tf_util.py:180-203) on channel-last rows: grad_weight (cout, cin) =
+ * grad_z^T x, fp32 MFMA, reduction over rows split into chunks whose partial tiles are summed in a fixed order.
+ * in_gamma != NULL: x is the previous layer's pre-BN output and relu(bn(x)) is applied while it is staged
+ * (in_gamma/in_beta/in_mean/in_invstd are that layer's (cin,) parameters and batch statistics). */
+size_t hf_linear_wgrad_workspace(long long rows, int cout, int cin);
+int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_z, const float *x, const float *in_gamma,
+                    const float *in_beta, const float *in_mean, const float *in_invstd, float *grad_weight,
+                    void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

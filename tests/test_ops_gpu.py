@@ -701,6 +701,20 @@ def test_stack_with_prefetched_geometry_matches_inline(hf):
             geo = pf2.get()
             pf2.submit(pts)
             assert torch.equal(net(pts, inten, geometry=geo), net(pts, inten))
+    # groups: the clouds of 3 batches sampled in one launch, results handed back batch by batch (a partial
+    # group at the end is flushed by get)
+    pf3 = GeometryPrefetcher(net.geometry, depth=2, group=3)
+    order = [xyz, xyz_b, xyz_b, xyz, xyz_b]
+    for pts in order[:4]:
+        pf3.submit(pts)
+    assert len(pf3) == 4 and pf3.capacity == 6
+    with torch.no_grad():
+        for i, pts in enumerate(order):
+            geo = pf3.get()
+            if i == 0:
+                pf3.submit(order[4])
+            assert torch.equal(net(pts, inten, geometry=geo), net(pts, inten))
+    assert len(pf3) == 0
 
 
 def test_sa_module_composition_against_oracle(hf, oracle_mod):
