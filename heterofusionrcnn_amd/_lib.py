@@ -57,6 +57,9 @@ _SIGNATURES = {
                                _sz, _vp],
     "hf_linear_wgrad_workspace": [ctypes.c_longlong, _i, _i],
     "hf_linear_wgrad": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_linear_bn_fwd_workspace": [_i],
+    "hf_linear_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
+                         _vp, _sz, _vp],
     "hf_version": [],
     "hf_strerror": [_i],
     "hf_last_hip_error": [],
@@ -67,6 +70,7 @@ _RESTYPES = {
     "hf_bn_workspace": _sz,
     "hf_three_nn_workspace": _sz,
     "hf_linear_wgrad_workspace": _sz,
+    "hf_linear_bn_fwd_workspace": _sz,
     "hf_version": ctypes.c_char_p,
     "hf_strerror": ctypes.c_char_p,
 }

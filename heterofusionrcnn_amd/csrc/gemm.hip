@@ -14,6 +14,10 @@
 //           one workgroup per (output tile, chunk); partial tiles are summed in a fixed order by a second
 //           kernel (deterministic, no atomics).  X may be given as the previous layer's pre-BN output: the
 //           BN affine + ReLU is then applied while staging ("activation on load").
+//   forward Z (R, Cout) = act(X) W^T + b plus the per-channel sum and sum of squares of Z (the BatchNorm batch
+//           statistics) from the accumulators, so the separate statistics pass over Z disappears; with activation
+//           on load the previous layer's normalised output is never written either.  A workgroup owns 128 rows
+//           and all Cout columns (<= 256): wave w holds rows 32w..32w+31 as Cout/32 accumulator tiles.
 #include <math.h>
 #include <stdint.h>
 
@@ -212,6 +216,139 @@ __global__ __launch_bounds__(64 * kWredGroups) void wgrad_reduce_kernel(int tota
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// forward: Z = act(X) W^T + bias, partial BN statistics of Z per workgroup
+// ------------------------------------------------------------------------------------------
+constexpr int kFwdRows = 128;   // rows per workgroup tile
+constexpr int kFwdKC = 32;      // input channels per LDS stage
+constexpr int kFwdLS = kFwdKC + 4;  // LDS row stride (keeps float4 stores aligned; 2-way read conflicts are noise here)
+constexpr int kFwdMaxCin = 1024;
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(kGemmThreads) void linear_fwd_kernel(long long rows, int cin, int cout, long long ntiles,
+                                                                  const float *__restrict__ X,
+                                                                  const float *__restrict__ in_gamma,
+                                                                  const float *__restrict__ in_beta,
+                                                                  const float *__restrict__ in_mean,
+                                                                  const float *__restrict__ in_invstd,
+                                                                  const float *__restrict__ W,
+                                                                  const float *__restrict__ bias, float *__restrict__ Z,
+                                                                  float *__restrict__ Hout, float *__restrict__ partial)
+{
+    __shared__ float As[kFwdRows * kFwdLS];
+    __shared__ float Bs[NT * 32 * kFwdLS];
+    __shared__ float red[4][NT * 32][2];
+    __shared__ float sc[kFwdMaxCin], sh[kFwdMaxCin];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool act = in_gamma != nullptr;
+    if (act) {
+        for (int k = t; k < cin; k += kGemmThreads) {
+            const float a = in_gamma[k] * in_invstd[k];
+            sc[k] = a;
+            sh[k] = in_beta[k] - in_mean[k] * a;
+        }
+    }
+    __syncthreads();
+
+    const int k4 = (t & 7) * 4, srow = t >> 3;  // staging: 8 threads cover the 32 channels of a row, 32 rows per pass
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = tile * kFwdRows;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
+
+        float4 ar[4], br[NT];
+        auto fetch = [&](int kc) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ar[p] = load4_guarded<VEC>(X, row0 + srow + 32 * p, rows, kc + k4, cin);
+#pragma unroll
+            for (int p = 0; p < NT; ++p) br[p] = load4_guarded<VEC>(W, srow + 32 * p, cout, kc + k4, cin);
+        };
+        fetch(0);
+        for (int kc = 0; kc < cin; kc += kFwdKC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 v = ar[p];
+                if (act) {  // rows / channels outside the matrix stay zero
+                    const bool rin = row0 + srow + 32 * p < rows;
+                    const int k = kc + k4;
+                    v.x = (rin && k < cin) ? fmaxf(sc[k] * v.x + sh[k], 0.f) : 0.f;
+                    v.y = (rin && k + 1 < cin) ? fmaxf(sc[k + 1] * v.y + sh[k + 1], 0.f) : 0.f;
+                    v.z = (rin && k + 2 < cin) ? fmaxf(sc[k + 2] * v.z + sh[k + 2], 0.f) : 0.f;
+                    v.w = (rin && k + 3 < cin) ? fmaxf(sc[k + 3] * v.w + sh[k + 3], 0.f) : 0.f;
+                    if (Hout && rin && k < cin) {  // the activated input, kept for the weight gradient
+                        float *h = Hout + (row0 + srow + 32 * p) * cin + k;
+                        if constexpr (VEC) {
+                            *reinterpret_cast<float4 *>(h) = v;
+                        } else {
+                            h[0] = v.x;
+                            if (k + 1 < cin) h[1] = v.y;
+                            if (k + 2 < cin) h[2] = v.z;
+                            if (k + 3 < cin) h[3] = v.w;
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(&As[(srow + 32 * p) * kFwdLS + k4]) = v;
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p) *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kFwdLS + k4]) = br[p];
+            __syncthreads();
+            if (kc + kFwdKC < cin) fetch(kc + kFwdKC);  // in flight during the MFMAs below
+            const float *ap = As + (32 * wave + (lane & 31)) * kFwdLS + (lane >> 5);
+            const float *bp = Bs + (lane & 31) * kFwdLS + (lane >> 5);
+#pragma unroll
+            for (int s = 0; s < kFwdKC / 2; ++s) {
+                const float a = ap[2 * s];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[nt * 32 * kFwdLS + 2 * s], acc[nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = nt * 32 + (lane & 31);
+            const bool cin_range = col < cout;
+            const float bv = (bias && cin_range) ? bias[col] : 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const long long row = row0 + 32 * wave + 8 * (g >> 2) + 4 * (lane >> 5) + (g & 3);
+                const float v = acc[nt][g] + bv;
+                if (cin_range && row < rows) {
+                    Z[row * cout + col] = v;
+                    s1[nt] += v;
+                    s2[nt] += v * v;
+                }
+            }
+        }
+    }
+    // per-workgroup column sums: the two row-halves of a wave, then the four waves in a fixed order
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
+        if (lane < 32) {
+            red[wave][nt * 32 + lane][0] = s1[nt];
+            red[wave][nt * 32 + lane][1] = s2[nt];
+        }
+    }
+    __syncthreads();
+    for (int col = t; col < cout; col += kGemmThreads) {
+        float a = red[0][col][0], b = red[0][col][1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { a += red[w][col][0]; b += red[w][col][1]; }
+        partial[static_cast<size_t>(col) * kBnMaxBlocks + blockIdx.x] = a;
+        partial[static_cast<size_t>(cout + col) * kBnMaxBlocks + blockIdx.x] = b;
+    }
+}
+
 struct WgradPlan {
     int wm, wn, mtiles, ntiles, chunks;
     long long rows_per_chunk;
@@ -277,5 +414,43 @@ HF_API int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_
     const int total = cout * cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(total, 64)), dim3(64 * kWredGroups), 0, st, total, p.chunks, partial,
                        grad_weight);
+    return launch_status();
+}
+
+HF_API size_t hf_linear_bn_fwd_workspace(int cout)
+{
+    return cout > 0 ? sizeof(float) * 2 * static_cast<size_t>(cout) * kBnMaxBlocks : 0;
+}
+
+HF_API int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,
+                            const float *in_mean, const float *in_invstd, float *x_act, const float *weight,
+                            const float *bias, float *z, float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd,
+                            void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows <= 0 || cin <= 0 || cout <= 0 || cin > kFwdMaxCin || cout > 256 || !x || !weight || !z || !mean || !invstd)
+        return HF_EINVAL;
+    if (in_gamma && (!in_beta || !in_mean || !in_invstd)) return HF_EINVAL;
+    if (x_act && !in_gamma) return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_linear_bn_fwd_workspace(cout)) return HF_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const long long ntiles = (rows + kFwdRows - 1) / kFwdRows;
+    const int nblk = static_cast<int>(ntiles < kBnMaxBlocks ? ntiles : kBnMaxBlocks);
+    const bool vec = vec4_ok(x, cin) && vec4_ok(weight, cin) && (!x_act || vec4_ok(x_act, cin));
+    const int nt = div_up(cout, 32);
+#define HF_FWD(N, V)                                                                                                    \
+    hipLaunchKernelGGL((linear_fwd_kernel<N, V>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, cin, cout, ntiles, x,    \
+                       in_gamma, in_beta, in_mean, in_invstd, weight, bias, z, x_act, partial)
+#define HF_FWD_V(N)                                                                                                     \
+    case N:                                                                                                             \
+        if (vec) HF_FWD(N, true); else HF_FWD(N, false);                                                                \
+        break
+    switch (nt) {
+        HF_FWD_V(1); HF_FWD_V(2); HF_FWD_V(3); HF_FWD_V(4); HF_FWD_V(5); HF_FWD_V(6); HF_FWD_V(7); HF_FWD_V(8);
+        default: return HF_EINVAL;
+    }
+#undef HF_FWD_V
+#undef HF_FWD
+    launch_bn_stats_finalize(rows, cout, nblk, partial, eps, momentum, running_mean, running_var, mean, invstd, st);
     return launch_status();
 }

@@ -20,6 +20,14 @@ inline int hip_status(hipError_t e)
     return HF_EHIP;
 }
 
+// BatchNorm partial-sum layout shared by mlp.hip and gemm.hip: partial[ch * kBnMaxBlocks + blk] = sum,
+// partial[(c + ch) * kBnMaxBlocks + blk] = sum of squares, blk < nblk <= kBnMaxBlocks
+constexpr int kBnMaxBlocks = 2048;
+// mlp.hip: fp64 reduction of the partials -> batch mean / invstd, running statistics update
+void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *partial, float eps, float momentum,
+                              float *running_mean, float *running_var, float *save_mean, float *save_invstd,
+                              hipStream_t st);
+
 // status of the launch that was just enqueued (no synchronisation)
 inline int launch_status() { return hip_status(hipGetLastError()); }
 

@@ -18,7 +18,6 @@
 
 namespace hf {
 
-constexpr int kBnMaxBlocks = 2048;
 
 struct BnGeom {
     int vec;       // floats per thread access (4 or 1)
@@ -442,6 +441,13 @@ __global__ void bn_pool_bwd_dx_kernel(long long rows, int k, int c, int cv, int 
                 colsum_partial[(static_cast<size_t>(cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = cs[i];
         }
     }
+}
+
+void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *partial, float eps, float momentum,
+                              float *running_mean, float *running_var, float *save_mean, float *save_invstd, hipStream_t st)
+{
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, nblk, partial, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd);
 }
 
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }

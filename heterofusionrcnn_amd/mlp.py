@@ -78,6 +78,129 @@ def linear_wgrad(grad_z, x, in_bn=None):
     return dw
 
 
+def linear_bn_fwd(x, weight, bias, bn, in_bn=None, keep_act=False):
+    """z = act(x) W^T + b and the batch statistics of z in one MFMA pass (csrc/gemm.hip).
+    Returns (z, mean, invstd, x_act); `bn` supplies eps / momentum / running buffers (updated in place).
+    in_bn = (gamma, beta, mean, invstd) of the previous layer: x is that layer's pre-BN output and relu(bn(x)) is
+    applied on load; keep_act also stores that activated input (x_act, else None)."""
+    rows, cin = x.shape
+    cout = weight.shape[0]
+    L = _lib.lib()
+    nbytes = L.hf_linear_bn_fwd_workspace(cout)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    mean = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    g, b, m, i = in_bn if in_bn is not None else (None, None, None, None)
+    x_act = torch.empty_like(x) if (keep_act and in_bn is not None) else None
+    check(L.hf_linear_bn_fwd(rows, cin, cout, ptr(x), ptr(g), ptr(b), ptr(m), ptr(i), ptr(x_act), ptr(weight), ptr(bias),
+                             ptr(z), bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(mean),
+                             ptr(invstd), ptr(ws), nbytes, stream_ptr()), "linear_bn_fwd")
+    return z, mean, invstd, x_act
+
+
+# the MFMA forward needs enough 128-row tiles to fill the chip; below this the library GEMM + separate passes win
+FUSED_FWD_MIN_ROWS = 32768
+
+
+class _SharedMLPChain(torch.autograd.Function):
+    """A whole shared MLP (tf_util.conv2d([1,1], bn=True) x L, pointnet_util.py:156-160) as ONE autograd node,
+    optionally ending in the max over the K grouped rows (:163-176).
+
+    Forward: layer l runs hf_linear_bn_fwd on the PREVIOUS layer's pre-BN output -- BN affine + ReLU applied while
+    the operand is staged, batch statistics of its own output taken from the accumulators -- so between two layers
+    there is no statistics pass and no separate normalisation pass; the activated input is stored once (the weight
+    gradient needs it).  The tail is either the fused BN+ReLU+max-pool or one BN+ReLU apply.
+    Backward: per layer the fused BN backward (dz, dgamma, dbeta), split-K dW, dX = dz W."""
+
+    @staticmethod
+    def forward(ctx, x, pool_k, layers, *params):
+        L = _lib.lib()
+        n = len(layers)
+        saved, cur, in_bn = [], x, None
+        for li, layer in enumerate(layers):
+            w, b, gamma, beta = params[4 * li:4 * li + 4]
+            z, mean, invstd, x_act = linear_bn_fwd(cur, w, b, layer.bn, in_bn, keep_act=True)
+            saved.append((x_act if x_act is not None else cur, z, mean, invstd))
+            cur, in_bn = z, (gamma, beta, mean, invstd)
+        gamma, beta, mean, invstd = in_bn
+        rows, cout = cur.shape
+        if pool_k:
+            groups = rows // pool_k
+            out = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
+            argmax = torch.empty((groups, cout), dtype=torch.uint8, device=x.device)
+            check(L.hf_bn_relu_maxpool_fwd(groups, pool_k, cout, ptr(cur), ptr(gamma), ptr(beta), 0, 0.0, 0.0, None, None,
+                                           ptr(mean), ptr(invstd), ptr(out), ptr(argmax), None, 0, stream_ptr()),
+                  "bn_relu_maxpool_fwd")
+        else:
+            argmax = None
+            out = torch.empty_like(cur)
+            check(L.hf_bn_relu_fwd_eval(rows, cout, ptr(cur), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), 1, ptr(out),
+                                        stream_ptr()), "bn_relu_apply")
+        flat = []
+        for t in saved:
+            flat.extend(t)
+        ctx.save_for_backward(*flat, *params, *([argmax] if argmax is not None else []))
+        ctx.n, ctx.pool_k = n, pool_k
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        n, pool_k = ctx.n, ctx.pool_k
+        tensors = ctx.saved_tensors
+        saved = [tensors[4 * i:4 * i + 4] for i in range(n)]
+        params = tensors[4 * n:8 * n]
+        argmax = tensors[8 * n] if pool_k else None
+        grads = [None] * (4 * n)
+        dy = dout.contiguous()
+        for li in range(n - 1, -1, -1):
+            xin, z, mean, invstd = saved[li]
+            w, b, gamma, beta = params[4 * li:4 * li + 4]
+            rows, cout = z.shape
+            dz = torch.empty_like(z)
+            dgamma, dbeta, dbias = torch.empty_like(gamma), torch.empty_like(beta), torch.empty_like(beta)
+            ws, nbytes = _workspace(rows, cout, z.device)
+            if li == n - 1 and pool_k:
+                check(L.hf_bn_relu_maxpool_bwd(rows // pool_k, pool_k, cout, ptr(z), ptr(dy), ptr(argmax), ptr(gamma),
+                                               ptr(beta), ptr(mean), ptr(invstd), ptr(dz), ptr(dgamma), ptr(dbeta),
+                                               ptr(dbias), ptr(ws), nbytes, stream_ptr()), "bn_relu_maxpool_bwd")
+            else:
+                check(L.hf_bn_relu_bwd(rows, cout, ptr(z), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), 1,
+                                       ptr(dz), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), nbytes, stream_ptr()),
+                      "bn_relu_bwd")
+            grads[4 * li:4 * li + 4] = [_splitk_wgrad(dz, xin), dbias, dgamma, dbeta]
+            if li > 0 or ctx.needs_input_grad[0]:
+                dy = dz @ w
+        return (dy if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
+def shared_mlp(layers, x, pool_k=0):
+    """x (R, Cin) through `layers` (SharedMLPLayer-like: .fc, .bn with relu) -> (R, Cout), or (R / pool_k, Cout) with
+    the max over each run of pool_k rows.  One fused node in training when every layer has BN+ReLU and the rows
+    fill the chip; otherwise layer by layer."""
+    layers = list(layers)
+    x = x.contiguous()
+    fused = (x.is_cuda and x.shape[0] >= FUSED_FWD_MIN_ROWS and all(l.bn is not None and l.bn.relu and l.bn.training
+                                                                    and l.fc.out_features <= 256 and l.fc.in_features <= 1024
+                                                                    for l in layers)
+             and (pool_k == 0 or (pool_k <= 255 and x.shape[0] % pool_k == 0)))
+    if fused:
+        params = []
+        for l in layers:
+            params += [l.fc.weight, l.fc.bias, l.bn.weight, l.bn.bias]
+        return _SharedMLPChain.apply(x, pool_k, layers, *params)
+    for l in layers[:-1] if pool_k else layers:
+        x = l(x)
+    if pool_k:
+        last = layers[-1]
+        if last.bn is not None and last.bn.relu and pool_k <= 255:
+            return linear_bn_relu_maxpool(x, last.fc.weight, last.fc.bias, last.bn, pool_k)
+        x = last(x)
+        return x.view(-1, pool_k, x.shape[-1]).max(dim=1).values
+    return x
+
+
 class _LinearBNReLU(torch.autograd.Function):
     """One autograd node for tf_util.conv2d([1,1], bn=True): z = x W^T + b; y = relu(bn(z)).
     Saves x and z only (y is never needed again); the BN backward pass also returns the column sums of dz,

@@ -22,7 +22,7 @@ import torch.nn as nn
 from .grouping import group_point, knn_point, query_ball_group, query_ball_point
 from .interpolate import INVERSE_MAX_KNOWN, three_interpolate, three_nn, three_nn_inverse
 from .sampling import farthest_point_sample, gather_point
-from .mlp import BatchNormReLU, linear_bn_relu, linear_bn_relu_maxpool
+from .mlp import BatchNormReLU, linear_bn_relu, shared_mlp
 from .bev_iou import compute_bev_iou as _compute_bev_iou, oriented_nms as _oriented_nms
 
 
@@ -172,18 +172,15 @@ class PointnetSAModule(nn.Module):
         else:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group(self.npoint, self.radius, self.nsample, xyz,
                                                                      points, self.knn, self.use_xyz)
+        bsz, npt, k, cin = new_points.shape
         last = self.mlp[-1]
-        fuse_pool = (self.pooling == "max" and last.bn is not None and last.relu and new_points.shape[2] <= 255 and
-                     new_points.is_cuda)
+        fuse_pool = (self.pooling == "max" and last.bn is not None and last.relu and k <= 255 and new_points.is_cuda)
         if fuse_pool:
-            # every layer but the last as usual; the last one fused with the max over the K grouped points
-            for layer in list(self.mlp)[:-1]:
-                new_points = layer(new_points)
-            bsz, npt, k, cin = new_points.shape
-            pooled = linear_bn_relu_maxpool(new_points.reshape(-1, cin), last.fc.weight, last.fc.bias, last.bn, k)
+            # the whole MLP and the max over the K grouped points as one node (mlp.shared_mlp)
+            pooled = shared_mlp(self.mlp, new_points.reshape(-1, cin), pool_k=k)
             new_points = pooled.reshape(bsz, npt, 1, -1)
         else:
-            new_points = self.mlp(new_points)
+            new_points = shared_mlp(self.mlp, new_points.reshape(-1, cin)).reshape(bsz, npt, k, -1)
         if fuse_pool:
             pass
         elif self.pooling == "max":
@@ -264,7 +261,8 @@ class PointnetFPModule(nn.Module):
         idx, weight, inverse = geom if geom is not None else self.geometry(xyz1, xyz2)
         interpolated = three_interpolate(points2, idx, weight, inverse if torch.is_grad_enabled() else None)
         new_points = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
-        return self.mlp(new_points)
+        bsz, npt, cin = new_points.shape
+        return shared_mlp(self.mlp, new_points.reshape(-1, cin)).reshape(bsz, npt, -1)
 
 
 class PointnetSAFPStack(nn.Module):

@@ -239,6 +239,20 @@ int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_z, cons
                     const float *in_beta, const float *in_mean, const float *in_invstd, float *grad_weight,
                     void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* tf_util.conv2d([1,1], bn=True) up to the batch statistics, one pass (tf_util.py:180-203, 554-581):
+ * z (rows, cout) = act(x) weight^T + bias on the fp32 MFMA, and the BatchNorm statistics of z (mean, invstd; running
+ * estimates updated) from the accumulators.  in_gamma != NULL: x is the PREVIOUS layer's pre-BN output and
+ * act = relu(bn(.)) with that layer's (cin,) parameters / statistics is applied while x is staged, so the normalised
+ * activation between two layers is not read back; in_gamma == NULL: x is used as is.  x_act (rows, cin), optional
+ * with in_gamma: the activated input is also stored (the weight gradient of this layer needs it in training).
+ * cout <= 256, cin <= 1024. */
+size_t hf_linear_bn_fwd_workspace(int cout);
+int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,
+                     const float *in_mean, const float *in_invstd, float *x_act, const float *weight, const float *bias,
+                     float *z,
+                     float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd,
+                     void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

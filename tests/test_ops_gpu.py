@@ -989,6 +989,54 @@ def test_fused_linear_bn_relu_node(hf, rows, cin, cout):
     assert layer.fc.bias.grad.abs().max() < 1e-2 and ref_fc.bias.grad.abs().max() < 1e-2
 
 
+@pytest.mark.parametrize("rows,pool_k,widths", [(32768, 32, (4, 32, 32, 64)), (40000, 0, (129, 128, 128)),
+                                                 (65536, 16, (67, 64, 96, 128)), (33000, 0, (5, 196, 256)),
+                                                 (4096, 32, (7, 16, 8))])
+def test_shared_mlp_chain_node(hf, rows, pool_k, widths):
+    """mlp.shared_mlp: a whole Linear+BN+ReLU stack (+ max over K rows) as one autograd node on the MFMA forward
+    kernel (statistics from the accumulators, BN+ReLU applied on load by the next layer), against
+    nn.Linear / nn.BatchNorm1d / relu / max.  The last case is below the row threshold: layer-by-layer path."""
+    from heterofusionrcnn_amd import modules
+    from heterofusionrcnn_amd.mlp import shared_mlp
+    torch.manual_seed(rows + pool_k)
+    layers = torch.nn.ModuleList([modules.SharedMLPLayer(a, b) for a, b in zip(widths[:-1], widths[1:])]).cuda()
+    ref = []
+    for l in layers:
+        fc = torch.nn.Linear(l.fc.in_features, l.fc.out_features).cuda()
+        bn = torch.nn.BatchNorm1d(l.fc.out_features, eps=1e-3, momentum=0.1).cuda()
+        with torch.no_grad():
+            l.fc.bias.uniform_(-.2, .2); l.bn.weight.uniform_(0.5, 1.5); l.bn.bias.uniform_(-.5, .5)
+            fc.weight.copy_(l.fc.weight); fc.bias.copy_(l.fc.bias); bn.weight.copy_(l.bn.weight); bn.bias.copy_(l.bn.bias)
+        ref.append((fc, bn))
+    x1 = torch.randn(rows, widths[0], device="cuda", requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1 = x1
+    for fc, bn in ref:
+        y1 = torch.relu(bn(fc(y1)))
+    if pool_k:
+        y1 = y1.view(rows // pool_k, pool_k, -1).max(dim=1).values
+    y2 = shared_mlp(layers, x2, pool_k)
+    torch.testing.assert_close(y2, y1, rtol=2e-4, atol=5e-5)
+    for l, (fc, bn) in zip(layers, ref):
+        torch.testing.assert_close(l.bn.running_mean, bn.running_mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(l.bn.running_var, bn.running_var, rtol=1e-4, atol=1e-5)
+    g = torch.randn_like(y1)
+    y1.backward(g); y2.backward(g)
+    # a pre-activation within rounding of zero may fall on the other side of the ReLU in the two implementations;
+    # that flips one unit for one row (expected a handful of times in ~1e7 activations): tolerate 1 row in 10^4
+    tol = 1e-3 * float(x1.grad.abs().max()) + 2e-5
+    bad_rows = ((x2.grad - x1.grad).abs() > tol + 2e-3 * x1.grad.abs()).any(dim=1).float().mean().item()
+    assert bad_rows <= 1e-4, bad_rows
+    for l, (fc, bn) in zip(layers, ref):
+        # sums over all rows: a flipped unit moves them by one row's contribution, bounded relative to the largest entry
+        # by about one row's contribution, in this layer and every layer below it: everything within 2% of the
+        # largest entry, and the mean error two orders of magnitude below that
+        for got, want in ((l.fc.weight.grad, fc.weight.grad), (l.bn.weight.grad, bn.weight.grad), (l.bn.bias.grad, bn.bias.grad)):
+            big = max(float(want.abs().max()), 1.0)
+            torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-2 * big)
+            assert (got - want).abs().mean().item() <= 5e-4 * big
+
+
 @pytest.mark.parametrize("groups,k,cin,cout", [(4096, 32, 32, 64), (333, 17, 7, 5), (1024, 64, 128, 256), (50, 255, 16, 24)])
 def test_fused_linear_bn_relu_maxpool_node(hf, groups, k, cin, cout):
     """mlp.linear_bn_relu_maxpool (Linear + BN + ReLU + max over the K grouped rows as one node; the dense
