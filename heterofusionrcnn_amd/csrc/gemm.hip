@@ -225,7 +225,7 @@ constexpr int kFwdLS = kFwdKC + 4;  // LDS row stride (keeps float4 stores align
 constexpr int kFwdMaxCin = 1024;
 
 template <int NT, bool VEC>
-__global__ __launch_bounds__(kGemmThreads) void linear_fwd_kernel(long long rows, int cin, int cout, long long ntiles,
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2))) void linear_fwd_kernel(long long rows, int cin, int cout, long long ntiles,
                                                                   const float *__restrict__ X,
                                                                   const float *__restrict__ in_gamma,
                                                                   const float *__restrict__ in_beta,
@@ -256,6 +256,14 @@ __global__ __launch_bounds__(kGemmThreads) void linear_fwd_kernel(long long rows
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
 
+    float4 ar[4], br[NT];
+    auto fetch = [&](long long r0, int kc) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ar[p] = load4_guarded<VEC>(X, r0 + srow + 32 * p, rows, kc + k4, cin);
+#pragma unroll
+        for (int p = 0; p < NT; ++p) br[p] = load4_guarded<VEC>(W, srow + 32 * p, cout, kc + k4, cin);
+    };
+    if (blockIdx.x < ntiles) fetch(static_cast<long long>(blockIdx.x) * kFwdRows, 0);
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long row0 = tile * kFwdRows;
         f32x16 acc[NT];
@@ -264,14 +272,6 @@ __global__ __launch_bounds__(kGemmThreads) void linear_fwd_kernel(long long rows
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
 
-        float4 ar[4], br[NT];
-        auto fetch = [&](int kc) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) ar[p] = load4_guarded<VEC>(X, row0 + srow + 32 * p, rows, kc + k4, cin);
-#pragma unroll
-            for (int p = 0; p < NT; ++p) br[p] = load4_guarded<VEC>(W, srow + 32 * p, cout, kc + k4, cin);
-        };
-        fetch(0);
         for (int kc = 0; kc < cin; kc += kFwdKC) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -300,10 +300,13 @@ __global__ __launch_bounds__(kGemmThreads) void linear_fwd_kernel(long long rows
 #pragma unroll
             for (int p = 0; p < NT; ++p) *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kFwdLS + k4]) = br[p];
             __syncthreads();
-            if (kc + kFwdKC < cin) fetch(kc + kFwdKC);  // in flight during the MFMAs below
+            // the next stage -- of this tile, or the first one of the workgroup's next tile -- is in flight during
+            // the MFMAs and the output stores below
+            if (kc + kFwdKC < cin) fetch(row0, kc + kFwdKC);
+            else if (tile + gridDim.x < ntiles) fetch((tile + gridDim.x) * kFwdRows, 0);
             const float *ap = As + (32 * wave + (lane & 31)) * kFwdLS + (lane >> 5);
             const float *bp = Bs + (lane & 31) * kFwdLS + (lane >> 5);
-#pragma unroll
+#pragma unroll 4
             for (int s = 0; s < kFwdKC / 2; ++s) {
                 const float a = ap[2 * s];
 #pragma unroll

@@ -491,6 +491,27 @@ HF_API int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const flo
     return launch_status();
 }
 
+HF_API int hf_bn_stats(long long rows, int c, const float *x, float eps, float momentum, float *running_mean,
+                       float *running_var, float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
+                       hf_stream_t stream)
+{
+    if (rows <= 0 || c <= 0 || c > 4096 || !x || !save_mean || !save_invstd) return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !aligned16(x)) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, partial);
+    else
+        hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, partial);
+    launch_bn_stats_finalize(rows, c, g.nblk, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd, st);
+    return launch_status();
+}
+
 HF_API int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const float *gamma, const float *beta,
                                const float *mean, const float *invstd, int relu, float *y, hf_stream_t stream)
 {

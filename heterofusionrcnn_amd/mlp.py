@@ -99,8 +99,32 @@ def linear_bn_fwd(x, weight, bias, bn, in_bn=None, keep_act=False):
     return z, mean, invstd, x_act
 
 
-# the MFMA forward needs enough 128-row tiles to fill the chip; below this the library GEMM + separate passes win
+# The MFMA forward pays off where the layer is bound by memory traffic: enough 128-row tiles to fill the chip and at
+# most 7 accumulator tiles per wave (Cout <= 224); wider / shorter layers keep the library GEMM plus a statistics pass
+# (scripts/gemm_fwd_probe.py).
 FUSED_FWD_MIN_ROWS = 32768
+FUSED_FWD_MAX_COUT = 224
+
+
+def _mfma_forward_pays(rows, cin, cout):
+    return rows >= FUSED_FWD_MIN_ROWS and cout <= FUSED_FWD_MAX_COUT and cin <= 1024
+
+
+def _bn_apply(z, gamma, beta, mean, invstd):
+    y = torch.empty_like(z)
+    check(_lib.lib().hf_bn_relu_fwd_eval(z.shape[0], z.shape[1], ptr(z), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), 1,
+                                         ptr(y), stream_ptr()), "bn_relu_apply")
+    return y
+
+
+def _bn_stats(z, bn):
+    rows, c = z.shape
+    mean = torch.empty((c,), dtype=torch.float32, device=z.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=z.device)
+    ws, nbytes = _workspace(rows, c, z.device)
+    check(_lib.lib().hf_bn_stats(rows, c, ptr(z), bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(mean),
+                                 ptr(invstd), ptr(ws), nbytes, stream_ptr()), "bn_stats")
+    return mean, invstd
 
 
 class _SharedMLPChain(torch.autograd.Function):
@@ -120,8 +144,14 @@ class _SharedMLPChain(torch.autograd.Function):
         saved, cur, in_bn = [], x, None
         for li, layer in enumerate(layers):
             w, b, gamma, beta = params[4 * li:4 * li + 4]
-            z, mean, invstd, x_act = linear_bn_fwd(cur, w, b, layer.bn, in_bn, keep_act=True)
-            saved.append((x_act if x_act is not None else cur, z, mean, invstd))
+            if _mfma_forward_pays(cur.shape[0], w.shape[1], w.shape[0]):
+                z, mean, invstd, x_act = linear_bn_fwd(cur, w, b, layer.bn, in_bn, keep_act=True)
+                xin = x_act if x_act is not None else cur
+            else:  # library GEMM on the materialised input, statistics in their own pass
+                xin = _bn_apply(cur, *in_bn) if in_bn is not None else cur
+                z = torch.addmm(b, xin, w.t())
+                mean, invstd = _bn_stats(z, layer.bn)
+            saved.append((xin, z, mean, invstd))
             cur, in_bn = z, (gamma, beta, mean, invstd)
         gamma, beta, mean, invstd = in_bn
         rows, cout = cur.shape
@@ -134,9 +164,7 @@ class _SharedMLPChain(torch.autograd.Function):
                   "bn_relu_maxpool_fwd")
         else:
             argmax = None
-            out = torch.empty_like(cur)
-            check(L.hf_bn_relu_fwd_eval(rows, cout, ptr(cur), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), 1, ptr(out),
-                                        stream_ptr()), "bn_relu_apply")
+            out = _bn_apply(cur, gamma, beta, mean, invstd)
         flat = []
         for t in saved:
             flat.extend(t)
@@ -177,13 +205,11 @@ class _SharedMLPChain(torch.autograd.Function):
 
 def shared_mlp(layers, x, pool_k=0):
     """x (R, Cin) through `layers` (SharedMLPLayer-like: .fc, .bn with relu) -> (R, Cout), or (R / pool_k, Cout) with
-    the max over each run of pool_k rows.  One fused node in training when every layer has BN+ReLU and the rows
-    fill the chip; otherwise layer by layer."""
+    the max over each run of pool_k rows.  One fused node in training when every layer has BN+ReLU (each layer on
+    the MFMA forward kernel where that pays, else library GEMM + statistics pass); otherwise layer by layer."""
     layers = list(layers)
     x = x.contiguous()
-    fused = (x.is_cuda and x.shape[0] >= FUSED_FWD_MIN_ROWS and all(l.bn is not None and l.bn.relu and l.bn.training
-                                                                    and l.fc.out_features <= 256 and l.fc.in_features <= 1024
-                                                                    for l in layers)
+    fused = (x.is_cuda and all(l.bn is not None and l.bn.relu and l.bn.training for l in layers)
              and (pool_k == 0 or (pool_k <= 255 and x.shape[0] % pool_k == 0)))
     if fused:
         params = []

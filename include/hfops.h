@@ -214,6 +214,11 @@ int hf_three_nn_inverse(int b, int n, int m, const int *idx, int *offsets, int *
 int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const float *grad_out, const float *weight,
                                         const int *offsets, const int *entries, float *grad_points, hf_stream_t stream);
 
+/* batch statistics only (the first half of hf_bn_relu_fwd_train): mean / invstd of x (rows, c) over rows, running
+ * estimates updated.  For callers that apply the normalisation elsewhere (fused into a pooling or a GEMM operand load). */
+int hf_bn_stats(long long rows, int c, const float *x, float eps, float momentum, float *running_mean, float *running_var,
+                float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 /* BN + ReLU + max over the k rows of every group, fused: the tail of a set-abstraction MLP
  * (tf_util.conv2d(..., bn=True) then tf.reduce_max(axis=[2]), pointnet_util.py:156-176).  z is (groups*k, c)
  * pre-BN; pooled is (groups, c).  training != 0: batch statistics are computed here (and the running estimates

@@ -21,13 +21,13 @@ for rows, cin, cout in shapes:
     x = torch.randn(rows, cin, device='cuda'); w = torch.randn(cout, cin, device='cuda') / cin ** .5; b = torch.randn(cout, device='cuda')
     bn = BatchNormReLU(cout).cuda(); bn_in = BatchNormReLU(cin).cuda()
     g = torch.rand(cin, device='cuda') + .5; be = torch.randn(cin, device='cuda'); mu = torch.randn(cin, device='cuda'); iv = torch.rand(cin, device='cuda') + .5
-    z, mean, invstd = linear_bn_fwd(x, w, b, bn)
+    z, mean, invstd, _ = linear_bn_fwd(x, w, b, bn)
     ref = x.double() @ w.double().t() + b.double()
     ez = ((z.double() - ref).abs().max() / ref.abs().max()).item()
     em = (mean.double() - ref.mean(0)).abs().max().item()
     ei = ((invstd.double() - 1 / (ref.var(0, unbiased=False) + bn.eps).sqrt()).abs().max() * ref.std(0).max()).item()
     h = torch.relu((x - mu) * iv * g + be)
-    z2, m2, i2 = linear_bn_fwd(x, w, b, bn, (g, be, mu, iv))
+    z2, m2, i2, _ = linear_bn_fwd(x, w, b, bn, (g, be, mu, iv))
     ref2 = h.double() @ w.double().t() + b.double()
     ez2 = ((z2.double() - ref2).abs().max() / ref2.abs().max()).item()
     em2 = (m2.double() - ref2.mean(0)).abs().max().item()
