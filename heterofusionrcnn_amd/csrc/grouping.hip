@@ -578,6 +578,50 @@ __global__ void group_point_grad_kernel(int n, int c, long long rows_per_batch, 
 }
 
 // ------------------------------------------------------------------------------------------
+// group_concat: the concat of sample_and_group (pointnet_util.py:58-60) written directly,
+//   out[b,j,k,:] = [ grouped_xyz[b,j,k,0:3], points[b, idx[b,j,k], 0:c], 0 ... ]   (row width `width` >= 3 + c)
+// instead of group_point into a temporary followed by a concat that reads and writes everything again.  The zero
+// columns pad rows to a multiple of 4 floats so that the GEMM that consumes them can use 16-byte accesses
+// (3 + C is never a multiple of 4 for the usual C = 64, 128).  One float4 of output per lane.
+// ------------------------------------------------------------------------------------------
+__global__ void group_concat_kernel(int n, int c, int w4, long long rows_per_batch, long long nrows,
+                                    const float *__restrict__ gxyz, const float *__restrict__ points,
+                                    const int *__restrict__ idx, float *__restrict__ out)
+{
+    const long long total = nrows * w4;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / w4;
+        const int q = static_cast<int>(e - row * w4);
+        const long long bb = row / rows_per_batch;
+        const float *src = points + (bb * n + idx[row]) * c - 3;  // column j of the output row is src[j] for 3 <= j < 3 + c
+        const float *g = gxyz + row * 3;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = q * 4 + i;
+            v[i] = j < 3 ? g[j] : (j < 3 + c ? src[j] : 0.0f);
+        }
+        *reinterpret_cast<float4 *>(out + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// gradient w.r.t. points: the feature columns 3..3+c of every row scattered back (target zeroed by the caller)
+__global__ void group_concat_grad_kernel(int n, int c, int width, long long rows_per_batch, long long nrows,
+                                         const float *__restrict__ grad_out, const int *__restrict__ idx,
+                                         float *__restrict__ grad_points)
+{
+    const long long total = nrows * c;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / c;
+        const int l = static_cast<int>(e - row * c);
+        const long long bb = row / rows_per_batch;
+        atomicAdd(grad_points + (bb * n + idx[row]) * c + l, grad_out[row * width + 3 + l]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // knn_point: the k nearest data points of every query, ascending (distance, index).
 // Caller side of the path: the reference builds a dense (b,m,n) distance
 // matrix |q|^2 - 2 q.p + |p|^2 with a batched matmul and takes tf.nn.top_k of its negation
@@ -846,6 +890,37 @@ HF_API int hf_group_point_grad(int b, int n, int c, int m, int nsample, const fl
     if (nrows == 0) return HF_OK;
     const int block = 256;
     hipLaunchKernelGGL(group_point_grad_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c,
+                       static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);
+    return launch_status();
+}
+
+HF_API int hf_group_concat(int b, int n, int c, int m, int nsample, int width, const float *grouped_xyz,
+                           const float *points, const int *idx, float *out, hf_stream_t stream)
+{
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || width < 3 + c || width % 4 != 0 || !grouped_xyz || !points ||
+        !idx || !out || reinterpret_cast<uintptr_t>(out) % 16 != 0)
+        return HF_EINVAL;
+    const long long nrows = static_cast<long long>(b) * m * nsample;
+    if (nrows == 0) return HF_OK;
+    const int block = 256;
+    hipLaunchKernelGGL(group_concat_kernel, dim3(grid_for(nrows * (width / 4), block)), dim3(block), 0, as_stream(stream), n,
+                       c, width / 4, static_cast<long long>(m) * nsample, nrows, grouped_xyz, points, idx, out);
+    return launch_status();
+}
+
+HF_API int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int width, const float *grad_out, const int *idx,
+                                float *grad_points, hf_stream_t stream)
+{
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || width < 3 + c || !grad_out || !idx || !grad_points)
+        return HF_EINVAL;
+    if (b == 0) return HF_OK;
+    hipStream_t st = as_stream(stream);
+    int rc = hip_status(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(b) * n * c, st));
+    if (rc != HF_OK) return rc;
+    const long long nrows = static_cast<long long>(b) * m * nsample;
+    if (nrows == 0) return HF_OK;
+    const int block = 256;
+    hipLaunchKernelGGL(group_concat_grad_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c, width,
                        static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);
     return launch_status();
 }

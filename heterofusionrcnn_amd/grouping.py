@@ -60,6 +60,47 @@ def group_point(points, idx):
     return _GroupPoint.apply(points, idx)
 
 
+class _GroupConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx, grouped_xyz, width):
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        out = torch.empty((b, m, ns, width), dtype=torch.float32, device=points.device)
+        check(_lib.lib().hf_group_concat(b, n, c, m, ns, width, ptr(grouped_xyz), ptr(points), ptr(idx), ptr(out),
+                                         stream_ptr()), "group_concat")
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, n, c, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, n, c, width = ctx.shape
+        _, m, ns = idx.shape
+        grad_out = grad_out.contiguous()
+        g = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
+        check(_lib.lib().hf_group_concat_grad(b, n, c, m, ns, width, ptr(grad_out), ptr(idx), ptr(g), stream_ptr()),
+              "group_concat_grad")
+        return g, None, None, None
+
+
+def group_concat(points, idx, grouped_xyz, width=None):
+    """[grouped_xyz, group_point(points, idx), zero padding] as one (B,M,K,width) tensor: the concat of
+    sample_and_group (pointnet_util.py:58-60) without the grouped temporary.  width defaults to 3 + C rounded up to
+    a multiple of 4.  Gradient w.r.t. points only (coordinates are inputs)."""
+    points = dev_tensor(points, torch.float32, "points")
+    idx = dev_tensor(idx, torch.int32, "idx")
+    grouped_xyz = dev_tensor(grouped_xyz.detach(), torch.float32, "grouped_xyz")
+    require(points.dim() == 3 and idx.dim() == 3 and idx.shape[0] == points.shape[0],
+            "GroupConcat expects (b,n,c) points and (b,m,k) idx")
+    require(grouped_xyz.shape == (*idx.shape, 3), "GroupConcat expects (b,m,k,3) grouped_xyz")
+    c = points.shape[2]
+    if width is None:
+        width = (3 + c + 3) // 4 * 4
+    require(width >= 3 + c and width % 4 == 0, "GroupConcat expects width >= 3 + c, a multiple of 4")
+    return _GroupConcat.apply(points, idx, grouped_xyz, width)
+
+
 def query_ball_group(radius, nsample, xyz1, xyz2, center=True):
     """Fused query_ball_point + group_point(xyz1, idx) [- xyz2]: the op pair of
     pointnet_util.py:48-52 / 258-260 in one launch.  Returns (idx, pts_cnt, grouped_xyz);

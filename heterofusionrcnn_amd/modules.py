@@ -19,7 +19,7 @@ kernels read and write coalesced.
 import torch
 import torch.nn as nn
 
-from .grouping import group_point, knn_point, query_ball_group, query_ball_point
+from .grouping import group_concat, group_point, knn_point, query_ball_group, query_ball_point
 from .interpolate import INVERSE_MAX_KNOWN, three_interpolate, three_nn, three_nn_inverse
 from .sampling import farthest_point_sample, gather_point
 from .mlp import BatchNormReLU, linear_bn_relu, shared_mlp
@@ -164,7 +164,10 @@ class PointnetSAModule(nn.Module):
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, self.use_xyz)
         elif geom is not None:
             new_xyz, idx, grouped_xyz = geom
-            if points is not None:
+            if points is not None and self.use_xyz and self.training and torch.is_grad_enabled():
+                # [xyz, features] rows written once, padded to a multiple of 4 columns (shared_mlp pads the weight)
+                new_points = group_concat(points, idx, grouped_xyz)
+            elif points is not None:
                 grouped_points = group_point(points, idx)
                 new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if self.use_xyz else grouped_points
             else:

@@ -717,6 +717,29 @@ def test_stack_with_prefetched_geometry_matches_inline(hf):
     assert len(pf3) == 0
 
 
+@pytest.mark.parametrize("c", [1, 5, 64, 127])
+def test_group_concat_against_group_point_and_cat(hf, c):
+    """grouping.group_concat = cat([grouped_xyz, group_point(points, idx)]) plus zero columns up to a multiple of 4,
+    bit for bit, and the same gradient w.r.t. points as the two-op form"""
+    from heterofusionrcnn_amd.grouping import group_concat
+    rng = np.random.default_rng(c)
+    b, n, m, k = 2, 300, 40, 8
+    pts = dev(rng.standard_normal((b, n, c)).astype(np.float32))
+    idx = dev(rng.integers(0, n, (b, m, k)).astype(np.int32))
+    gxyz = dev(rng.standard_normal((b, m, k, 3)).astype(np.float32))
+    p1 = pts.clone().requires_grad_(True); p2 = pts.clone().requires_grad_(True)
+    out = group_concat(p1, idx, gxyz)
+    width = (3 + c + 3) // 4 * 4
+    assert out.shape == (b, m, k, width)
+    ref = torch.cat([gxyz, hf.group_point(p2, idx)], dim=-1)
+    assert torch.equal(out[..., :3 + c], ref) and bool((out[..., 3 + c:] == 0).all())
+    g = torch.randn_like(out)
+    out.backward(g); ref.backward(g[..., :3 + c].contiguous())
+    torch.testing.assert_close(p1.grad, p2.grad, rtol=1e-5, atol=1e-5)  # atomics: summation order differs
+    with pytest.raises(ValueError):
+        group_concat(pts, idx, gxyz, width=3 + c + 1 if (3 + c + 1) % 4 else 3 + c - 1)
+
+
 def test_sa_module_composition_against_oracle(hf, oracle_mod):
     """sample_and_group restated from pointnet_util.py:24-66: op order, centring, concat order [xyz, feats]"""
     from heterofusionrcnn_amd import modules
