@@ -236,6 +236,50 @@ __global__ void three_interpolate_cl_kernel(int m, int c, long long n_per_batch,
     }
 }
 
+// three_interpolate written straight into the concat of pointnet_fp_module (pointnet_util.py:311-313):
+//   out[b,j,:] = [ sum_t w_t * points[b, idx_t, 0:c], skip[b,j,0:c1], 0 ... ]      (row width `width`, multiple of 4)
+// One float4 of output per lane; VEC4: c % 4 == 0, so a float4 never straddles the two sources.
+template <bool VEC4>
+__global__ void three_interpolate_concat_kernel(int m, int c, int c1, int w4, long long n_per_batch, long long nrows,
+                                                const float *__restrict__ points, const int *__restrict__ idx,
+                                                const float *__restrict__ weight, const float *__restrict__ skip,
+                                                float *__restrict__ out)
+{
+    const long long total = nrows * w4;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / w4;
+        const int q = static_cast<int>(e - row * w4);
+        const long long bb = row / n_per_batch;
+        const int *k = idx + row * 3;
+        const float *w = weight + row * 3;
+        const float *base = points + bb * m * c;
+        float v[4];
+        if (VEC4 && q * 4 + 3 < c) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(base + static_cast<size_t>(k[0]) * c + q * 4);
+            const float4 p1 = *reinterpret_cast<const float4 *>(base + static_cast<size_t>(k[1]) * c + q * 4);
+            const float4 p2 = *reinterpret_cast<const float4 *>(base + static_cast<size_t>(k[2]) * c + q * 4);
+            v[0] = w[0] * p0.x + w[1] * p1.x + w[2] * p2.x;  // left to right, no contraction: as three_interpolate
+            v[1] = w[0] * p0.y + w[1] * p1.y + w[2] * p2.y;
+            v[2] = w[0] * p0.z + w[1] * p1.z + w[2] * p2.z;
+            v[3] = w[0] * p0.w + w[1] * p1.w + w[2] * p2.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = q * 4 + i;
+                if (j < c)
+                    v[i] = w[0] * base[static_cast<size_t>(k[0]) * c + j] + w[1] * base[static_cast<size_t>(k[1]) * c + j] +
+                           w[2] * base[static_cast<size_t>(k[2]) * c + j];
+                else if (j < c + c1)
+                    v[i] = skip[row * c1 + (j - c)];
+                else
+                    v[i] = 0.0f;
+            }
+        }
+        *reinterpret_cast<float4 *>(out + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 __global__ void three_interpolate_cl_grad_kernel(int m, int c, long long n_per_batch, long long nrows,
                                                  const float *__restrict__ grad_out, const int *__restrict__ idx,
                                                  const float *__restrict__ weight, float *__restrict__ grad_points)
@@ -320,7 +364,7 @@ __global__ __launch_bounds__(kInvThreads) void three_nn_inverse_kernel(int n, in
 }
 
 template <int VEC>
-__global__ void three_interpolate_cl_grad_gather_kernel(int n, int m, int c, int cv, long long known_rows,
+__global__ void three_interpolate_cl_grad_gather_kernel(int n, int m, int c, int ld, int cv, long long known_rows,
                                                         const float *__restrict__ grad_out,
                                                         const float *__restrict__ weight,
                                                         const int *__restrict__ offsets,
@@ -336,7 +380,7 @@ __global__ void three_interpolate_cl_grad_gather_kernel(int n, int m, int c, int
         const int k = static_cast<int>(row - bb * m);
         const int *off = offsets + bb * (m + 1);
         const int *ent = entries + bb * 3ll * n;
-        const float *go = grad_out + bb * n * c + cvec * VEC;
+        const float *go = grad_out + bb * n * ld + cvec * VEC;  // ld: row stride of grad_out (>= c)
         const float *w = weight + bb * 3ll * n;
         float acc[VEC];
 #pragma unroll
@@ -345,7 +389,7 @@ __global__ void three_interpolate_cl_grad_gather_kernel(int n, int m, int c, int
         for (int a = lo; a < hi; ++a) {
             const int e = ent[a];
             const float wt = w[e];
-            const float *src = go + static_cast<long long>(e / 3) * c;
+            const float *src = go + static_cast<long long>(e / 3) * ld;
             if constexpr (VEC == 4) {
                 const float4 v = *reinterpret_cast<const float4 *>(src);
                 acc[0] += v.x * wt; acc[1] += v.y * wt; acc[2] += v.z * wt; acc[3] += v.w * wt;
@@ -454,15 +498,16 @@ HF_API int hf_three_nn_inverse(int b, int n, int m, const int *idx, int *offsets
     return launch_status();
 }
 
-HF_API int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const float *grad_out, const float *weight,
-                                               const int *offsets, const int *entries, float *grad_points,
-                                               hf_stream_t stream)
+static int interpolate_grad_gather(int b, int n, int c, int ld, int m, const float *grad_out, const float *weight,
+                                   const int *offsets, const int *entries, float *grad_points, hf_stream_t stream)
 {
-    if (b < 0 || n < 0 || c < 0 || m <= 0 || !offsets || !grad_points || (n > 0 && c > 0 && (!grad_out || !weight || !entries)))
+    if (b < 0 || n < 0 || c < 0 || ld < c || m <= 0 || !offsets || !grad_points ||
+        (n > 0 && c > 0 && (!grad_out || !weight || !entries)))
         return HF_EINVAL;
     const long long known_rows = static_cast<long long>(b) * m;
     if (known_rows == 0 || c == 0) return HF_OK;
-    const bool vec4 = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_points)) % 16 == 0);
+    const bool vec4 = (c % 4 == 0) && (ld % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_points)) % 16 == 0);
     const int cv = vec4 ? c / 4 : c;
     if (cv > 1024) return HF_EINVAL;
     int block = 256;
@@ -472,10 +517,10 @@ HF_API int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const
     if (grid > kNumCU * 64ll) grid = kNumCU * 64ll;
     if (vec4)
         hipLaunchKernelGGL((three_interpolate_cl_grad_gather_kernel<4>), dim3(static_cast<unsigned>(grid)), dim3(block), 0,
-                           as_stream(stream), n, m, c, cv, known_rows, grad_out, weight, offsets, entries, grad_points);
+                           as_stream(stream), n, m, c, ld, cv, known_rows, grad_out, weight, offsets, entries, grad_points);
     else
         hipLaunchKernelGGL((three_interpolate_cl_grad_gather_kernel<1>), dim3(static_cast<unsigned>(grid)), dim3(block), 0,
-                           as_stream(stream), n, m, c, cv, known_rows, grad_out, weight, offsets, entries, grad_points);
+                           as_stream(stream), n, m, c, ld, cv, known_rows, grad_out, weight, offsets, entries, grad_points);
     return launch_status();
 }
 
@@ -519,4 +564,37 @@ HF_API int hf_three_nn_sorted(int b, int n, int m, const float *unknown, const f
     hipLaunchKernelGGL(three_nn_sweep_kernel, dim3(div_up(n, kNnThreads), b), dim3(kNnThreads), sweep_lds, st, n, m,
                        unknown, sorted, dist2, idx);
     return launch_status();
+}
+
+HF_API int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const float *grad_out, const float *weight,
+                                               const int *offsets, const int *entries, float *grad_points,
+                                               hf_stream_t stream)
+{
+    return interpolate_grad_gather(b, n, c, c, m, grad_out, weight, offsets, entries, grad_points, stream);
+}
+
+HF_API int hf_three_interpolate_concat(int b, int m, int c, int n, int c1, int width, const float *points, const int *idx,
+                                       const float *weight, const float *skip, float *out, hf_stream_t stream)
+{
+    if (b < 0 || c <= 0 || m <= 0 || n < 0 || c1 < 0 || width < c + c1 || width % 4 != 0 || !points || !idx || !weight ||
+        !out || (c1 > 0 && !skip) || reinterpret_cast<uintptr_t>(out) % 16 != 0)
+        return HF_EINVAL;
+    const long long nrows = static_cast<long long>(b) * n;
+    if (nrows == 0) return HF_OK;
+    const int block = 256;
+    const dim3 grid(grid_for(nrows * (width / 4), block));
+    const bool vec4 = c % 4 == 0 && reinterpret_cast<uintptr_t>(points) % 16 == 0;
+    if (vec4)
+        hipLaunchKernelGGL((three_interpolate_concat_kernel<true>), grid, dim3(block), 0, as_stream(stream), m, c, c1, width / 4,
+                           static_cast<long long>(n), nrows, points, idx, weight, skip, out);
+    else
+        hipLaunchKernelGGL((three_interpolate_concat_kernel<false>), grid, dim3(block), 0, as_stream(stream), m, c, c1,
+                           width / 4, static_cast<long long>(n), nrows, points, idx, weight, skip, out);
+    return launch_status();
+}
+
+HF_API int hf_three_interpolate_concat_grad(int b, int n, int c, int m, int width, const float *grad_out, const float *weight,
+                                            const int *offsets, const int *entries, float *grad_points, hf_stream_t stream)
+{
+    return interpolate_grad_gather(b, n, c, width, m, grad_out, weight, offsets, entries, grad_points, stream);
 }

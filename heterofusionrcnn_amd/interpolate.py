@@ -84,6 +84,59 @@ class _ThreeInterpolateInv(torch.autograd.Function):
         return g, None, None, None, None
 
 
+class _InterpolateConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, skip, idx, weight, offsets, entries, width):
+        b, m, c = points.shape
+        n = idx.shape[1]
+        c1 = skip.shape[2] if skip is not None else 0
+        out = torch.empty((b, n, width), dtype=torch.float32, device=points.device)
+        check(_lib.lib().hf_three_interpolate_concat(b, m, c, n, c1, width, ptr(points), ptr(idx), ptr(weight), ptr(skip),
+                                                     ptr(out), stream_ptr()), "three_interpolate_concat")
+        ctx.save_for_backward(weight, offsets, entries)
+        ctx.shape = (b, m, c, n, c1, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        weight, offsets, entries = ctx.saved_tensors
+        b, m, c, n, c1, width = ctx.shape
+        grad_out = grad_out.contiguous()
+        g = None
+        if ctx.needs_input_grad[0]:
+            g = torch.empty((b, m, c), dtype=torch.float32, device=grad_out.device)
+            check(_lib.lib().hf_three_interpolate_concat_grad(b, n, c, m, width, ptr(grad_out), ptr(weight), ptr(offsets),
+                                                              ptr(entries), ptr(g), stream_ptr()),
+                  "three_interpolate_concat_grad")
+        gskip = grad_out[:, :, c:c + c1] if (c1 and ctx.needs_input_grad[1]) else None
+        return g, gskip, None, None, None, None, None
+
+
+def three_interpolate_concat(points, skip, idx, weight, inverse, width=None):
+    """[three_interpolate(points, idx, weight), skip, zero padding] as one (B,N,width) tensor: the concat of
+    pointnet_fp_module (pointnet_util.py:311-313) without the interpolated temporary.  width defaults to C + C1
+    rounded up to a multiple of 4.  `inverse` = three_nn_inverse(idx, M); gradients w.r.t. points and skip."""
+    points = dev_tensor(points, torch.float32, "points")
+    idx = dev_tensor(idx, torch.int32, "idx")
+    weight = dev_tensor(weight.detach(), torch.float32, "weight")
+    require(points.dim() == 3 and idx.dim() == 3 and idx.shape[2] == 3 and weight.shape == idx.shape,
+            "ThreeInterpolate expects (b,m,c) points and (b,n,3) idx / weight")
+    c1 = 0
+    if skip is not None:
+        skip = dev_tensor(skip, torch.float32, "skip")
+        require(skip.dim() == 3 and skip.shape[:2] == idx.shape[:2], "skip features must be (b,n,c1)")
+        c1 = skip.shape[2]
+    c = points.shape[2]
+    if width is None:
+        width = (c + c1 + 3) // 4 * 4
+    require(width >= c + c1 and width % 4 == 0, "width must be >= c + c1 and a multiple of 4")
+    offsets, entries = inverse
+    require(offsets.shape == (points.shape[0], points.shape[1] + 1) and entries.shape == (idx.shape[0], 3 * idx.shape[1]),
+            "ThreeInterpolate expects the inverse of this idx: offsets (b,m+1), entries (b,3n)")
+    return _InterpolateConcat.apply(points, skip, idx, weight, dev_tensor(offsets, torch.int32, "offsets"),
+                                    dev_tensor(entries, torch.int32, "entries"), width)
+
+
 class _ThreeInterpolate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx, weight):

@@ -20,7 +20,8 @@ import torch
 import torch.nn as nn
 
 from .grouping import group_concat, group_point, knn_point, query_ball_group, query_ball_point
-from .interpolate import INVERSE_MAX_KNOWN, three_interpolate, three_nn, three_nn_inverse
+from .interpolate import (INVERSE_MAX_KNOWN, three_interpolate, three_interpolate_concat, three_nn,
+                          three_nn_inverse)
 from .sampling import farthest_point_sample, gather_point
 from .mlp import BatchNormReLU, linear_bn_relu, shared_mlp
 from .bev_iou import compute_bev_iou as _compute_bev_iou, oriented_nms as _oriented_nms
@@ -262,8 +263,12 @@ class PointnetFPModule(nn.Module):
 
     def forward(self, xyz1, xyz2, points1, points2, geom=None):
         idx, weight, inverse = geom if geom is not None else self.geometry(xyz1, xyz2)
-        interpolated = three_interpolate(points2, idx, weight, inverse if torch.is_grad_enabled() else None)
-        new_points = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
+        if inverse is not None and self.training and torch.is_grad_enabled():
+            # [interpolated, skip] rows written once, padded to a multiple of 4 columns (shared_mlp pads the weight)
+            new_points = three_interpolate_concat(points2, points1, idx, weight, inverse)
+        else:
+            interpolated = three_interpolate(points2, idx, weight, inverse if torch.is_grad_enabled() else None)
+            new_points = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
         bsz, npt, cin = new_points.shape
         return shared_mlp(self.mlp, new_points.reshape(-1, cin)).reshape(bsz, npt, -1)
 

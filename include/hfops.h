@@ -227,6 +227,15 @@ int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const float 
 int hf_bn_stats(long long rows, int c, const float *x, float eps, float momentum, float *running_mean, float *running_var,
                 float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* three_interpolate written into the concat of pointnet_fp_module (pointnet_util.py:311-313): out (b, n, width) rows are
+ * [interpolated (c), skip (c1), zeros]; width >= c + c1, width % 4 == 0; skip (b, n, c1) may be NULL when c1 == 0.
+ * hf_three_interpolate_concat_grad: gradient w.r.t. points from the first c columns of grad_out (b, n, width), gather
+ * form over the inverse index (see hf_three_nn_inverse). */
+int hf_three_interpolate_concat(int b, int m, int c, int n, int c1, int width, const float *points, const int *idx,
+                                const float *weight, const float *skip, float *out, hf_stream_t stream);
+int hf_three_interpolate_concat_grad(int b, int n, int c, int m, int width, const float *grad_out, const float *weight,
+                                     const int *offsets, const int *entries, float *grad_points, hf_stream_t stream);
+
 /* BN + ReLU + max over the k rows of every group, fused: the tail of a set-abstraction MLP
  * (tf_util.conv2d(..., bn=True) then tf.reduce_max(axis=[2]), pointnet_util.py:156-176).  z is (groups*k, c)
  * pre-BN; pooled is (groups, c).  training != 0: batch statistics are computed here (and the running estimates

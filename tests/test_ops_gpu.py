@@ -346,6 +346,34 @@ def test_three_nn_inverse_and_gather_gradient(hf, oracle_mod, b, n, m, c):
     assert np.array_equal(host(p.grad), oracle_mod.three_interpolate_grad(pts.shape, idx3, w, go))
 
 
+@pytest.mark.parametrize("c,c1", [(128, 1), (16, 16), (30, 0), (7, 5)])
+def test_three_interpolate_concat_against_interpolate_and_cat(hf, c, c1):
+    """interpolate.three_interpolate_concat = cat([three_interpolate(points2), points1]) plus zero columns, bit for
+    bit; gradients w.r.t. both feature tensors equal the two-op form's (gather form: same summation order)"""
+    from heterofusionrcnn_amd.interpolate import three_interpolate_concat, three_nn_inverse
+    rng = np.random.default_rng(c + c1)
+    b, n, m = 2, 700, 90
+    idx3 = dev(rng.integers(0, m, (b, n, 3)).astype(np.int32))
+    w = dev(rng.random((b, n, 3), dtype=np.float32))
+    inv = three_nn_inverse(idx3, m)
+    p2 = dev(rng.standard_normal((b, m, c)).astype(np.float32))
+    p1 = dev(rng.standard_normal((b, n, c1)).astype(np.float32)) if c1 else None
+    a2 = p2.clone().requires_grad_(True); b2 = p2.clone().requires_grad_(True)
+    a1 = p1.clone().requires_grad_(True) if c1 else None
+    b1 = p1.clone().requires_grad_(True) if c1 else None
+    out = three_interpolate_concat(a2, a1, idx3, w, inv)
+    width = (c + c1 + 3) // 4 * 4
+    assert out.shape == (b, n, width)
+    interp = hf.three_interpolate(b2, idx3, w, inverse=inv)
+    ref = torch.cat([interp, b1], dim=2) if c1 else interp
+    assert torch.equal(out[..., :c + c1], ref) and bool((out[..., c + c1:] == 0).all())
+    g = torch.randn_like(out)
+    out.backward(g); ref.backward(g[..., :c + c1].contiguous())
+    assert torch.equal(a2.grad, b2.grad)
+    if c1:
+        assert torch.equal(a1.grad, b1.grad)
+
+
 def test_three_nn_inverse_drops_out_of_range(hf):
     from heterofusionrcnn_amd.interpolate import three_nn_inverse
     idx3 = np.array([[[0, 5, 1], [-1, 1, 2], [1, 1, 99]]], np.int32)
