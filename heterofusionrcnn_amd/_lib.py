@@ -65,6 +65,9 @@ _SIGNATURES = {
     "hf_linear_bn_fwd_workspace": [_i],
     "hf_linear_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
                          _vp, _sz, _vp],
+    "hf_bn_relu_bwd_dx": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "hf_linear_bn_bwd_workspace": [_i],
+    "hf_linear_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 18 + [_vp, _sz, _vp],
     "hf_version": [],
     "hf_strerror": [_i],
     "hf_last_hip_error": [],
@@ -76,6 +79,7 @@ _RESTYPES = {
     "hf_three_nn_workspace": _sz,
     "hf_linear_wgrad_workspace": _sz,
     "hf_linear_bn_fwd_workspace": _sz,
+    "hf_linear_bn_bwd_workspace": _sz,
     "hf_version": ctypes.c_char_p,
     "hf_strerror": ctypes.c_char_p,
 }

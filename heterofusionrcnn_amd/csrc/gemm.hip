@@ -352,6 +352,174 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward (input gradient): DX (R, Cin) = DZ (R, Cout) W, the same tall-skinny shape as the forward with the roles
+// (X, W) -> (DZ, W^T).  Two things ride along:
+//   * DZ on load (FROM_DY): the operand is not read but rebuilt while it is staged, from the gradient DY w.r.t. this
+//     layer's activation, its pre-BN output Z and its BN constants -- dz = a (dh - dbeta/R - xhat dgamma/R) with
+//     dh = dy where the ReLU was active -- and written out once for the weight gradient.  The separate BN-backward
+//     "dx" pass disappears.
+//   * the BN-backward sums of the layer BELOW (its dbeta = sum dh', dgamma = sum dh' xhat', dh' = DX masked by that
+//     layer's ReLU) are taken from the accumulators in the epilogue, reading that layer's pre-BN output once.  The
+//     separate BN-backward "reduce" pass disappears.
+// WT is W transposed, (Cin, Cout) row-major (a few KB, transposed by the caller).
+// ------------------------------------------------------------------------------------------
+constexpr int kBwdMaxK = 256;  // Cout of the layer (the K dimension here): six per-channel tables in LDS
+
+template <int NT, bool VEC, bool FROM_DY>
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2))) void linear_bwd_kernel(
+    long long rows, int kdim, int ncols, long long ntiles, const float *__restrict__ DY, const float *__restrict__ Z,
+    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+    float *__restrict__ DZ_out, const float *__restrict__ WT, float *__restrict__ DX, const float *__restrict__ Zprev,
+    const float *__restrict__ p_gamma, const float *__restrict__ p_beta, const float *__restrict__ p_mean,
+    const float *__restrict__ p_invstd, float *__restrict__ partial)
+{
+    __shared__ float As[kFwdRows * kFwdLS];
+    __shared__ float Bs[NT * 32 * kFwdLS];
+    __shared__ float red[4][NT * 32][2];
+    __shared__ float ta[FROM_DY ? kBwdMaxK : 1], tsh[FROM_DY ? kBwdMaxK : 1], tmu[FROM_DY ? kBwdMaxK : 1],
+        tis[FROM_DY ? kBwdMaxK : 1], tc1[FROM_DY ? kBwdMaxK : 1], tc2[FROM_DY ? kBwdMaxK : 1];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (FROM_DY) {
+        const float inv_r = 1.0f / static_cast<float>(rows);
+        for (int k = t; k < kdim; k += kGemmThreads) {
+            const float a = gamma[k] * invstd[k];
+            ta[k] = a;
+            tsh[k] = beta[k] - mean[k] * a;
+            tmu[k] = mean[k];
+            tis[k] = invstd[k];
+            tc1[k] = dbeta[k] * inv_r;
+            tc2[k] = dgamma[k] * inv_r;
+        }
+    }
+    __syncthreads();
+    const bool sums = Zprev != nullptr;
+    // BN constants of the layer below for this lane's output columns
+    float pa[NT], psh[NT], pmu[NT], pis[NT], s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 32 + (lane & 31);
+        pa[nt] = 0.f; psh[nt] = 0.f; pmu[nt] = 0.f; pis[nt] = 0.f; s1[nt] = 0.f; s2[nt] = 0.f;
+        if (sums && col < ncols) {
+            pa[nt] = p_gamma[col] * p_invstd[col];
+            psh[nt] = p_beta[col] - p_mean[col] * pa[nt];
+            pmu[nt] = p_mean[col];
+            pis[nt] = p_invstd[col];
+        }
+    }
+
+    const int k4 = (t & 7) * 4, srow = t >> 3;
+    float4 ar[4], zr[4], br[NT];
+    auto fetch = [&](long long r0, int kc) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ar[p] = load4_guarded<VEC>(DY, r0 + srow + 32 * p, rows, kc + k4, kdim);
+            if (FROM_DY) zr[p] = load4_guarded<VEC>(Z, r0 + srow + 32 * p, rows, kc + k4, kdim);
+        }
+#pragma unroll
+        for (int p = 0; p < NT; ++p) br[p] = load4_guarded<VEC>(WT, srow + 32 * p, ncols, kc + k4, kdim);
+    };
+    if (blockIdx.x < ntiles) fetch(static_cast<long long>(blockIdx.x) * kFwdRows, 0);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = tile * kFwdRows;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
+
+        for (int kc = 0; kc < kdim; kc += kFwdKC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 v = ar[p];
+                if (FROM_DY) {
+                    const bool rin = row0 + srow + 32 * p < rows;
+                    const int k = kc + k4;
+                    float d[4] = { v.x, v.y, v.z, v.w };
+                    const float zz[4] = { zr[p].x, zr[p].y, zr[p].z, zr[p].w };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (rin && k + i < kdim) {
+                            const float a = ta[k + i];
+                            const float dh = (a * zz[i] + tsh[k + i] > 0.0f) ? d[i] : 0.0f;
+                            const float xhat = (zz[i] - tmu[k + i]) * tis[k + i];
+                            d[i] = a * (dh - tc1[k + i] - xhat * tc2[k + i]);
+                        } else {
+                            d[i] = 0.0f;
+                        }
+                    }
+                    v = make_float4(d[0], d[1], d[2], d[3]);
+                    if (DZ_out && rin && k < kdim) {
+                        float *o = DZ_out + (row0 + srow + 32 * p) * kdim + k;
+                        if constexpr (VEC) {
+                            *reinterpret_cast<float4 *>(o) = v;
+                        } else {
+                            o[0] = v.x;
+                            if (k + 1 < kdim) o[1] = v.y;
+                            if (k + 2 < kdim) o[2] = v.z;
+                            if (k + 3 < kdim) o[3] = v.w;
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(&As[(srow + 32 * p) * kFwdLS + k4]) = v;
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p) *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kFwdLS + k4]) = br[p];
+            __syncthreads();
+            if (kc + kFwdKC < kdim) fetch(row0, kc + kFwdKC);
+            else if (tile + gridDim.x < ntiles) fetch((tile + gridDim.x) * kFwdRows, 0);
+            const float *ap = As + (32 * wave + (lane & 31)) * kFwdLS + (lane >> 5);
+            const float *bp = Bs + (lane & 31) * kFwdLS + (lane >> 5);
+#pragma unroll 4
+            for (int s = 0; s < kFwdKC / 2; ++s) {
+                const float a = ap[2 * s];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[nt * 32 * kFwdLS + 2 * s], acc[nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = nt * 32 + (lane & 31);
+            if (col >= ncols) continue;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const long long row = row0 + 32 * wave + 8 * (g >> 2) + 4 * (lane >> 5) + (g & 3);
+                if (row >= rows) continue;
+                const float v = acc[nt][g];
+                if (DX) DX[row * ncols + col] = v;
+                if (sums) {
+                    const float zp = Zprev[row * ncols + col];
+                    const float dh = (pa[nt] * zp + psh[nt] > 0.0f) ? v : 0.0f;
+                    s1[nt] += dh;
+                    s2[nt] += dh * ((zp - pmu[nt]) * pis[nt]);
+                }
+            }
+        }
+    }
+    if (!sums) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
+        if (lane < 32) {
+            red[wave][nt * 32 + lane][0] = s1[nt];
+            red[wave][nt * 32 + lane][1] = s2[nt];
+        }
+    }
+    __syncthreads();
+    for (int col = t; col < ncols; col += kGemmThreads) {
+        float a = red[0][col][0], b = red[0][col][1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { a += red[w][col][0]; b += red[w][col][1]; }
+        partial[static_cast<size_t>(col) * kBnMaxBlocks + blockIdx.x] = a;
+        partial[static_cast<size_t>(ncols + col) * kBnMaxBlocks + blockIdx.x] = b;
+    }
+}
+
 struct WgradPlan {
     int wm, wn, mtiles, ntiles, chunks;
     long long rows_per_chunk;
@@ -455,5 +623,52 @@ HF_API int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, c
 #undef HF_FWD_V
 #undef HF_FWD
     launch_bn_stats_finalize(rows, cout, nblk, partial, eps, momentum, running_mean, running_var, mean, invstd, st);
+    return launch_status();
+}
+
+HF_API size_t hf_linear_bn_bwd_workspace(int cin)
+{
+    return cin > 0 ? sizeof(float) * 2 * static_cast<size_t>(cin) * kBnMaxBlocks : 0;
+}
+
+HF_API int hf_linear_bn_bwd(long long rows, int cout, int cin, const float *dy_or_dz, const float *z, const float *gamma,
+                            const float *beta, const float *mean, const float *invstd, const float *dgamma,
+                            const float *dbeta, float *dz_out, const float *weight_t, float *dx, const float *z_prev,
+                            const float *p_gamma, const float *p_beta, const float *p_mean, const float *p_invstd,
+                            float *p_dgamma, float *p_dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows <= 0 || cout <= 0 || cin <= 0 || cin > 256 || !dy_or_dz || !weight_t) return HF_EINVAL;
+    const bool from_dy = z != nullptr;
+    if (from_dy && (cout > kBwdMaxK || !gamma || !beta || !mean || !invstd || !dgamma || !dbeta)) return HF_EINVAL;
+    if (!from_dy && dz_out) return HF_EINVAL;
+    const bool sums = z_prev != nullptr;
+    if (sums && (!p_gamma || !p_beta || !p_mean || !p_invstd || !p_dgamma || !p_dbeta)) return HF_EINVAL;
+    if (sums && (!workspace || workspace_bytes < hf_linear_bn_bwd_workspace(cin))) return HF_EWORKSPACE;
+    if (!dx && !sums && !dz_out) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const long long ntiles = (rows + kFwdRows - 1) / kFwdRows;
+    const int nblk = static_cast<int>(ntiles < kBnMaxBlocks ? ntiles : kBnMaxBlocks);
+    const bool vec = vec4_ok(dy_or_dz, cout) && vec4_ok(weight_t, cout) && (!from_dy || vec4_ok(z, cout)) &&
+                     (!dz_out || vec4_ok(dz_out, cout));
+    const int nt = div_up(cin, 32);
+#define HF_BWD(N, V, F)                                                                                                 \
+    hipLaunchKernelGGL((linear_bwd_kernel<N, V, F>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, cout, cin, ntiles,     \
+                       dy_or_dz, z, gamma, beta, mean, invstd, dgamma, dbeta, dz_out, weight_t, dx, z_prev, p_gamma,   \
+                       p_beta, p_mean, p_invstd, partial)
+#define HF_BWD_N(N)                                                                                                     \
+    case N:                                                                                                             \
+        if (vec && from_dy) HF_BWD(N, true, true);                                                                      \
+        else if (vec) HF_BWD(N, true, false);                                                                           \
+        else if (from_dy) HF_BWD(N, false, true);                                                                       \
+        else HF_BWD(N, false, false);                                                                                   \
+        break
+    switch (nt) {
+        HF_BWD_N(1); HF_BWD_N(2); HF_BWD_N(3); HF_BWD_N(4); HF_BWD_N(5); HF_BWD_N(6); HF_BWD_N(7); HF_BWD_N(8);
+        default: return HF_EINVAL;
+    }
+#undef HF_BWD_N
+#undef HF_BWD
+    if (sums) launch_bn_bwd_finalize(cin, nblk, partial, p_dgamma, p_dbeta, st);
     return launch_status();
 }

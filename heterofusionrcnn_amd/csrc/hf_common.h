@@ -27,6 +27,8 @@ constexpr int kBnMaxBlocks = 2048;
 void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *partial, float eps, float momentum,
                               float *running_mean, float *running_var, float *save_mean, float *save_invstd,
                               hipStream_t st);
+// mlp.hip: fp64 reduction of BN-backward partials (sum dh, sum dh*xhat) -> dbeta, dgamma
+void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma, float *dbeta, hipStream_t st);
 
 // status of the launch that was just enqueued (no synchronisation)
 inline int launch_status() { return hip_status(hipGetLastError()); }

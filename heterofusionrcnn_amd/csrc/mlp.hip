@@ -450,6 +450,11 @@ void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *part
                        running_mean, running_var, save_mean, save_invstd);
 }
 
+void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma, float *dbeta, hipStream_t st)
+{
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, nblk, partial, dgamma, dbeta);
+}
+
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 }  // namespace hf
@@ -557,6 +562,28 @@ HF_API int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy
                            g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart);
     if (dx_colsum)
         hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, cpart, dx_colsum);
+    return launch_status();
+}
+
+HF_API int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
+                             const float *save_mean, const float *save_invstd, const float *dgamma, const float *dbeta,
+                             int relu, float *dx, hf_stream_t stream)
+{
+    if (rows <= 0 || c <= 0 || c > 4096 || !x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma ||
+        !dbeta)
+        return HF_EINVAL;
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx))) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx,
+                           static_cast<float *>(nullptr));
+    else
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx,
+                           static_cast<float *>(nullptr));
     return launch_status();
 }
 

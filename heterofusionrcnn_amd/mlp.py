@@ -112,6 +112,11 @@ def _mfma_forward_pays(rows, cin, cout):
     return rows >= FUSED_FWD_MIN_ROWS and cout <= FUSED_FWD_MAX_COUT and cin <= 1024
 
 
+def _mfma_backward_pays(rows, cin, cout):
+    # the input-gradient kernel holds Cin / 32 accumulator tiles per wave; beyond 5 it spills
+    return rows >= FUSED_FWD_MIN_ROWS and cin <= 160 and cout <= 256
+
+
 def _bn_apply(z, gamma, beta, mean, invstd):
     y = torch.empty_like(z)
     check(_lib.lib().hf_bn_relu_fwd_eval(z.shape[0], z.shape[1], ptr(z), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), 1,
@@ -184,28 +189,64 @@ class _SharedMLPChain(torch.autograd.Function):
         argmax = tensors[8 * n] if pool_k else None
         grads = [None] * (4 * n)
         dy = dout.contiguous()
+        known = None  # (dgamma, dbeta) of the layer about to be processed, when the layer above already reduced them
         for li in range(n - 1, -1, -1):
             xin, z, mean, invstd = saved[li]
             w, b, gamma, beta = params[4 * li:4 * li + 4]
             rows, cout = z.shape
-            dz = torch.empty_like(z)
-            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+            cin = w.shape[1]
+            need_dx = li > 0 or ctx.needs_input_grad[0]
+            mfma = need_dx and _mfma_backward_pays(rows, cin, cout)
             # A bias that feeds a batch norm has an exactly zero gradient: sum_r dz[r, c] = a_c (sum dh - R c1 - c2 sum xhat)
             # with c1 = sum dh / R and sum xhat = 0.  The column sums the kernels can also produce are rounding noise
             # around that zero (what autodiff frameworks return); the exact value is returned here and the pass skipped.
             dbias = torch.zeros_like(beta)
-            ws, nbytes = _workspace(rows, cout, z.device)
-            if li == n - 1 and pool_k:
-                check(L.hf_bn_relu_maxpool_bwd(rows // pool_k, pool_k, cout, ptr(z), ptr(dy), ptr(argmax), ptr(gamma),
-                                               ptr(beta), ptr(mean), ptr(invstd), ptr(dz), ptr(dgamma), ptr(dbeta),
-                                               None, ptr(ws), nbytes, stream_ptr()), "bn_relu_maxpool_bwd")
+            dz, from_dy = None, False
+            if known is None:  # reduce + dx passes of the BN backward (the pooled tail has its own pair)
+                dz = torch.empty_like(z)
+                dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+                ws, nbytes = _workspace(rows, cout, z.device)
+                if li == n - 1 and pool_k:
+                    check(L.hf_bn_relu_maxpool_bwd(rows // pool_k, pool_k, cout, ptr(z), ptr(dy), ptr(argmax), ptr(gamma),
+                                                   ptr(beta), ptr(mean), ptr(invstd), ptr(dz), ptr(dgamma), ptr(dbeta),
+                                                   None, ptr(ws), nbytes, stream_ptr()), "bn_relu_maxpool_bwd")
+                else:
+                    check(L.hf_bn_relu_bwd(rows, cout, ptr(z), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), 1,
+                                           ptr(dz), ptr(dgamma), ptr(dbeta), None, ptr(ws), nbytes, stream_ptr()),
+                          "bn_relu_bwd")
             else:
-                check(L.hf_bn_relu_bwd(rows, cout, ptr(z), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), 1,
-                                       ptr(dz), ptr(dgamma), ptr(dbeta), None, ptr(ws), nbytes, stream_ptr()),
-                      "bn_relu_bwd")
-            grads[4 * li:4 * li + 4] = [_splitk_wgrad(dz, xin), dbias, dgamma, dbeta]
-            if li > 0 or ctx.needs_input_grad[0]:
+                dgamma, dbeta = known
+                if mfma:
+                    from_dy = True  # dz is rebuilt inside the input-gradient kernel while its operand is staged
+                else:
+                    dz = torch.empty_like(z)
+                    check(L.hf_bn_relu_bwd_dx(rows, cout, ptr(z), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
+                                              ptr(dgamma), ptr(dbeta), 1, ptr(dz), stream_ptr()), "bn_relu_bwd_dx")
+            known = None
+            if mfma:
+                wt = w.t().contiguous()
+                dx = torch.empty((rows, cin), dtype=torch.float32, device=z.device)
+                if from_dy:
+                    dz = torch.empty_like(z)
+                if li > 0:  # the BN-backward sums of the layer below come out of this kernel's accumulators
+                    pz, pmean, pinv = saved[li - 1][1:4]
+                    pgamma, pbeta = params[4 * (li - 1) + 2], params[4 * (li - 1) + 3]
+                    pdg, pdb = torch.empty_like(pgamma), torch.empty_like(pbeta)
+                    nbytes = L.hf_linear_bn_bwd_workspace(cin)
+                    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=z.device)
+                    known = (pdg, pdb)
+                else:
+                    pz = pmean = pinv = pgamma = pbeta = pdg = pdb = ws = None
+                    nbytes = 0
+                check(L.hf_linear_bn_bwd(rows, cout, cin, ptr(dy if from_dy else dz), ptr(z) if from_dy else None,
+                                         ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
+                                         ptr(dz) if from_dy else None, ptr(wt), ptr(dx), ptr(pz), ptr(pgamma), ptr(pbeta),
+                                         ptr(pmean), ptr(pinv), ptr(pdg), ptr(pdb), ptr(ws), nbytes, stream_ptr()),
+                      "linear_bn_bwd")
+                dy = dx
+            elif need_dx:
                 dy = dz @ w
+            grads[4 * li:4 * li + 4] = [_splitk_wgrad(dz, xin), dbias, dgamma, dbeta]
         return (dy if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 

@@ -275,6 +275,23 @@ int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, const fl
                      float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd,
                      void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* The second half of hf_bn_relu_bwd alone: dx from dy, x and ALREADY KNOWN dgamma / dbeta (no reduction pass). */
+int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
+                      const float *save_mean, const float *save_invstd, const float *dgamma, const float *dbeta, int relu,
+                      float *dx, hf_stream_t stream);
+/* Input gradient of tf_util.conv2d([1,1], bn=True) on the fp32 MFMA: dx (rows, cin) = dz (rows, cout) W, weight_t = W^T
+ * as (cin, cout).  z != NULL: the first operand is dy, the gradient w.r.t. this layer's activation, and dz is rebuilt
+ * from (dy, z, gamma, beta, mean, invstd, dgamma, dbeta) while it is staged (and stored to dz_out if given); z == NULL:
+ * the first operand is dz itself.  z_prev != NULL: dgamma / dbeta of the layer below (p_*: its parameters and
+ * statistics, z_prev (rows, cin) its pre-BN output) are reduced from the accumulators into p_dgamma / p_dbeta.
+ * dx may be NULL when only dz_out / the sums are wanted.  cin <= 256, cout <= 256 with z. */
+size_t hf_linear_bn_bwd_workspace(int cin);
+int hf_linear_bn_bwd(long long rows, int cout, int cin, const float *dy_or_dz, const float *z, const float *gamma,
+                     const float *beta, const float *mean, const float *invstd, const float *dgamma, const float *dbeta,
+                     float *dz_out, const float *weight_t, float *dx, const float *z_prev, const float *p_gamma,
+                     const float *p_beta, const float *p_mean, const float *p_invstd, float *p_dgamma, float *p_dbeta,
+                     void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
