@@ -78,9 +78,11 @@ def wrap_model(model, ctx, bucket_cap_mb=64):
         return model
     from torch.nn.parallel import DistributedDataParallel
     if ctx.device.type == "cuda":
+        # per-replica BatchNorm statistics as under Horovod (hf/core/trainer.py:71 averages gradients only):
+        # no per-step broadcast of the running buffers
         return DistributedDataParallel(model, device_ids=[ctx.local_rank], bucket_cap_mb=bucket_cap_mb,
-                                       gradient_as_bucket_view=True)
-    return DistributedDataParallel(model, bucket_cap_mb=bucket_cap_mb)
+                                       gradient_as_bucket_view=True, broadcast_buffers=False)
+    return DistributedDataParallel(model, bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
 
 
 def fence(ctx):
