@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+SURVEY_TWO_OP_BYTES = 24641536  # query_ball_point 6 291 456 + group_point 18 350 080 at B=8, N=16384, M=4096, K=32, C=3
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 B, N0, KNN = 8, 16384, 32
@@ -283,8 +284,8 @@ def main():
     xyz = torch.from_numpy(kitti_uniform(rng, B, N0)).cuda()
     intensity = torch.from_numpy(rng.uniform(-0.5, 0.5, (B, N0, 1)).astype(np.float32)).cuda()
 
-    from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
-    group = args.prefetch_group or max(g for g in range(1, 9) if args.steps % g == 0)
+    from heterofusionrcnn_amd.pipeline import GeometryPrefetcher, choose_group
+    group = args.prefetch_group or choose_group(args.steps)
     prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth, group=group)
 
     def step():
@@ -342,7 +343,11 @@ def main():
             "roofline": {"kernel": "query_ball_point+group_point fused (hf_query_ball_group_xyz), B=8 N=16384 M=4096 K=32",
                          "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                         "traffic": measured_traffic(), "algorithmic_bytes": algo, "avg_launch_us": round(k_us, 3) if k_us else None,
+                         "traffic": measured_traffic(), "algorithmic_bytes": algo,
+                         # SURVEY.md 8(d) prices the two separate ops (idx written then re-read, xyz read twice):
+                         # 24 641 536 B; the fused kernel's compulsory traffic is `algorithmic_bytes` (used for frac)
+                         "survey_8d_two_op_bytes": SURVEY_TWO_OP_BYTES,
+                         "frac_vs_survey_8d_bytes": round(SURVEY_TWO_OP_BYTES / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if k_us else None, "avg_launch_us": round(k_us, 3) if k_us else None,
                          "launches_timed": n_burst,
                          "in_step_avg_launch_us": round(in_step_us, 3) if in_step_us else None,
                          "in_step_launches": len(timer.pairs),

@@ -190,6 +190,12 @@ class _SharedMLPChain(torch.autograd.Function):
         grads = [None] * (4 * n)
         dy = dout.contiguous()
         known = None  # (dgamma, dbeta) of the layer about to be processed, when the layer above already reduced them
+        # A bias that feeds a batch norm has an exactly zero gradient: sum_r dz[r, c] = a_c (sum dh - R c1 - c2 sum xhat)
+        # with c1 = sum dh / R and sum xhat = 0.  The column sums the kernels can also produce are rounding noise
+        # around that zero (what autodiff frameworks return); the exact value is returned and the pass skipped.
+        # One zero buffer for the whole node, one slice per layer.
+        couts = [params[4 * i].shape[0] for i in range(n)]
+        zero_bias = torch.zeros((sum(couts),), dtype=torch.float32, device=dy.device)
         for li in range(n - 1, -1, -1):
             xin, z, mean, invstd = saved[li]
             w, b, gamma, beta = params[4 * li:4 * li + 4]
@@ -197,10 +203,7 @@ class _SharedMLPChain(torch.autograd.Function):
             cin = w.shape[1]
             need_dx = li > 0 or ctx.needs_input_grad[0]
             mfma = need_dx and _mfma_backward_pays(rows, cin, cout)
-            # A bias that feeds a batch norm has an exactly zero gradient: sum_r dz[r, c] = a_c (sum dh - R c1 - c2 sum xhat)
-            # with c1 = sum dh / R and sum xhat = 0.  The column sums the kernels can also produce are rounding noise
-            # around that zero (what autodiff frameworks return); the exact value is returned here and the pass skipped.
-            dbias = torch.zeros_like(beta)
+            dbias = zero_bias[sum(couts[:li]):sum(couts[:li + 1])]
             dz, from_dy = None, False
             if known is None:  # reduce + dx passes of the BN backward (the pooled tail has its own pair)
                 dz = torch.empty_like(z)

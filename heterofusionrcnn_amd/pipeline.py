@@ -22,6 +22,13 @@ def _walk(obj, fn):
             _walk(v, fn)
 
 
+def choose_group(steps, largest=8):
+    """batches per geometry launch for a run of `steps` timed steps: the largest divisor of `steps` up to `largest`,
+    so that the run launches the geometry of exactly as many batches as it consumes"""
+    steps = int(steps)
+    return max(g for g in range(1, largest + 1) if steps % g == 0) if steps > 0 else 1
+
+
 def _slice_frames(obj, lo, hi):
     """frames [lo, hi) of every tensor in a nested geometry result (all of them are batch-major)"""
     if isinstance(obj, torch.Tensor):
