@@ -20,6 +20,7 @@
 //           and all Cout columns (<= 256): wave w holds rows 32w..32w+31 as Cout/32 accumulator tiles.
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hf_common.h"
 
@@ -543,6 +544,23 @@ static WgradPlan wgrad_plan(long long rows, int cout, int cin)
     return p;
 }
 
+// Persistent tile loops: as many workgroups as are resident at once (LDS / VGPR bound per accumulator-tile count),
+// times HF_GEMM_ROUNDS (default 2: whole rounds, and a tail that costs half as much when sampling pins a few CUs).
+static int resident_grid(int nt, long long ntiles)
+{
+    static const int per_cu[9] = { 0, 5, 4, 3, 3, 2, 2, 2, 2 };
+    static int rounds = -1;
+    if (rounds < 0) {
+        const char *e = getenv("HF_GEMM_ROUNDS");
+        rounds = e ? atoi(e) : 2;
+        if (rounds < 1) rounds = 1;
+    }
+    long long g = static_cast<long long>(kNumCU) * per_cu[nt < 1 ? 1 : (nt > 8 ? 8 : nt)] * rounds;
+    if (g > kBnMaxBlocks) g = kBnMaxBlocks;
+    if (g > ntiles) g = ntiles;
+    return static_cast<int>(g);
+}
+
 static bool vec4_ok(const void *p, int ncols) { return ncols % 4 == 0 && reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 }  // namespace hf
@@ -606,9 +624,9 @@ HF_API int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, c
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     const long long ntiles = (rows + kFwdRows - 1) / kFwdRows;
-    const int nblk = static_cast<int>(ntiles < kBnMaxBlocks ? ntiles : kBnMaxBlocks);
     const bool vec = vec4_ok(x, cin) && vec4_ok(weight, cin) && (!x_act || vec4_ok(x_act, cin));
     const int nt = div_up(cout, 32);
+    const int nblk = resident_grid(nt, ntiles);
 #define HF_FWD(N, V)                                                                                                    \
     hipLaunchKernelGGL((linear_fwd_kernel<N, V>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, cin, cout, ntiles, x,    \
                        in_gamma, in_beta, in_mean, in_invstd, weight, bias, z, x_act, partial)
@@ -648,7 +666,7 @@ HF_API int hf_linear_bn_bwd(long long rows, int cout, int cin, const float *dy_o
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     const long long ntiles = (rows + kFwdRows - 1) / kFwdRows;
-    const int nblk = static_cast<int>(ntiles < kBnMaxBlocks ? ntiles : kBnMaxBlocks);
+    const int nblk = resident_grid(div_up(cin, 32), ntiles);
     const bool vec = vec4_ok(dy_or_dz, cout) && vec4_ok(weight_t, cout) && (!from_dy || vec4_ok(z, cout)) &&
                      (!dz_out || vec4_ok(dz_out, cout));
     const int nt = div_up(cin, 32);
