@@ -191,6 +191,19 @@ def per_op_table(hf, xyz):
     us = time_op(lambda: det(xyz, intensity_for_infer(xyz)), iters=3, warm=1)
     t["two_stage_infer_ms_per_batch8"] = us / 1e3
     t["two_stage_infer_frames_per_s"] = B / (us * 1e-6)
+    # the same flow with the RPN geometry of the next batches computed ahead on side streams (two_stage.run_sharded)
+    from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
+    pf = GeometryPrefetcher(det.rpn.geometry, depth=2)
+    inten0 = intensity_for_infer(xyz)
+    pf.submit(xyz); pf.submit(xyz)
+
+    def piped():
+        geo = pf.get()
+        pf.submit(xyz)
+        det(xyz, inten0, geometry=geo)
+    us = time_op(piped, iters=6, warm=2)
+    t["two_stage_infer_pipelined_ms_per_batch8"] = us / 1e3
+    t["two_stage_infer_pipelined_frames_per_s"] = B / (us * 1e-6)
     return {k: round(v, 3) for k, v in t.items()}
 
 

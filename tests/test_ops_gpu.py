@@ -921,6 +921,15 @@ def test_two_stage_inference_flow(hf, oracle_mod):
     ctx = dp.DPContext(0, 1, 0, torch.device("cuda", 0))
     merged = run_sharded(det, [xyz[0], xyz[1]], [inten[0], inten[1]], ctx, frames_per_batch=2)
     assert sorted(merged) == [0, 1] and torch.equal(merged[0]["boxes"], dets[0]["boxes"].cpu())
+    # more batches than prefetch slots (geometry of batch i+2 submitted while batch i runs): same detections as
+    # the unpipelined model, frame by frame
+    frames = [xyz[0], xyz[1], xyz[1], xyz[0], xyz[1]]
+    intens = [inten[0], inten[1], inten[1], inten[0], inten[1]]
+    piped = run_sharded(det, frames, intens, ctx, frames_per_batch=1)
+    assert sorted(piped) == [0, 1, 2, 3, 4]
+    for j, (f, it) in enumerate(zip(frames, intens)):
+        alone = det(f[None], it[None])[0]
+        assert torch.equal(piped[j]["boxes"], alone["boxes"].cpu()) and torch.equal(piped[j]["scores"], alone["scores"].cpu())
 
 
 def test_batched_nms_equals_per_frame(hf, oracle_mod):
