@@ -80,11 +80,12 @@ def linear_wgrad(grad_z, x, in_bn=None):
     return dw
 
 
-def linear_bn_fwd(x, weight, bias, bn, in_bn=None, keep_act=False):
+def linear_bn_fwd(x, weight, bias, bn, in_bn=None, keep_act=False, update_running=True):
     """z = act(x) W^T + b and the batch statistics of z in one MFMA pass (csrc/gemm.hip).
     Returns (z, mean, invstd, x_act); `bn` supplies eps / momentum / running buffers (updated in place).
     in_bn = (gamma, beta, mean, invstd) of the previous layer: x is that layer's pre-BN output and relu(bn(x)) is
-    applied on load; keep_act also stores that activated input (x_act, else None)."""
+    applied on load; keep_act also stores that activated input (x_act, else None); update_running=False leaves the
+    running estimates alone (inference: the returned batch statistics are then simply not used)."""
     rows, cin = x.shape
     cout = weight.shape[0]
     L = _lib.lib()
@@ -96,7 +97,8 @@ def linear_bn_fwd(x, weight, bias, bn, in_bn=None, keep_act=False):
     g, b, m, i = in_bn if in_bn is not None else (None, None, None, None)
     x_act = torch.empty_like(x) if (keep_act and in_bn is not None) else None
     check(L.hf_linear_bn_fwd(rows, cin, cout, ptr(x), ptr(g), ptr(b), ptr(m), ptr(i), ptr(x_act), ptr(weight), ptr(bias),
-                             ptr(z), bn.eps, bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(mean),
+                             ptr(z), bn.eps, bn.momentum, ptr(bn.running_mean) if update_running else None,
+                             ptr(bn.running_var) if update_running else None, ptr(mean),
                              ptr(invstd), ptr(ws), nbytes, stream_ptr()), "linear_bn_fwd")
     return z, mean, invstd, x_act
 
@@ -253,14 +255,38 @@ class _SharedMLPChain(torch.autograd.Function):
         return (dy if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 
+def _shared_mlp_eval(layers, x, pool_k, extra):
+    """inference twin of _SharedMLPChain.forward: running statistics instead of batch statistics, nothing saved"""
+    L = _lib.lib()
+    cur, in_bn = x, None
+    for i, layer in enumerate(layers):
+        w = layer.fc.weight if (i or not extra) else torch.nn.functional.pad(layer.fc.weight, (0, extra))
+        bn = layer.bn
+        if _mfma_forward_pays(cur.shape[0], w.shape[1], w.shape[0]):
+            z = linear_bn_fwd(cur, w, layer.fc.bias, bn, in_bn, update_running=False)[0]
+        else:
+            xin = _bn_apply(cur, *in_bn) if in_bn is not None else cur
+            z = torch.addmm(layer.fc.bias, xin, w.t())
+        cur, in_bn = z, (bn.weight, bn.bias, bn.running_mean, torch.rsqrt(bn.running_var + bn.eps))
+    gamma, beta, mean, invstd = in_bn
+    if not pool_k:
+        return _bn_apply(cur, gamma, beta, mean, invstd)
+    rows, cout = cur.shape
+    out = torch.empty((rows // pool_k, cout), dtype=torch.float32, device=x.device)
+    check(L.hf_bn_relu_maxpool_fwd(rows // pool_k, pool_k, cout, ptr(cur), ptr(gamma), ptr(beta), 0, 0.0, 0.0, None, None,
+                                   ptr(mean), ptr(invstd), ptr(out), None, None, 0, stream_ptr()), "bn_relu_maxpool_fwd")
+    return out
+
+
 def shared_mlp(layers, x, pool_k=0):
     """x (R, Cin) through `layers` (SharedMLPLayer-like: .fc, .bn with relu) -> (R, Cout), or (R / pool_k, Cout) with
     the max over each run of pool_k rows.  One fused node in training when every layer has BN+ReLU (each layer on
     the MFMA forward kernel where that pays, else library GEMM + statistics pass); otherwise layer by layer."""
     layers = list(layers)
     x = x.contiguous()
-    fused = (x.is_cuda and all(l.bn is not None and l.bn.relu and l.bn.training for l in layers)
-             and (pool_k == 0 or (pool_k <= 255 and x.shape[0] % pool_k == 0)))
+    bn_relu = x.is_cuda and all(l.bn is not None and l.bn.relu for l in layers)
+    pool_ok = pool_k == 0 or (pool_k <= 255 and x.shape[0] % pool_k == 0)
+    fused = bn_relu and pool_ok and all(l.bn.training for l in layers)
     extra = x.shape[1] - layers[0].fc.in_features  # zero columns appended by the producer (grouping.group_concat)
     assert extra >= 0
     if fused:
@@ -269,6 +295,8 @@ def shared_mlp(layers, x, pool_k=0):
             w = l.fc.weight if (i or not extra) else torch.nn.functional.pad(l.fc.weight, (0, extra))
             params += [w, l.fc.bias, l.bn.weight, l.bn.bias]
         return _SharedMLPChain.apply(x, pool_k, layers, *params)
+    if bn_relu and pool_ok and not torch.is_grad_enabled() and not any(l.bn.training for l in layers):
+        return _shared_mlp_eval(layers, x, pool_k, extra)
     if extra:
         x = x[:, :layers[0].fc.in_features]
     for l in layers[:-1] if pool_k else layers:

@@ -163,14 +163,14 @@ class PointnetSAModule(nn.Module):
     def forward(self, xyz, points, geom=None):
         if self.group_all:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, self.use_xyz)
-        elif geom is not None:
-            new_xyz, idx, grouped_xyz = geom
-            if points is not None and self.use_xyz and self.training and torch.is_grad_enabled():
+        elif geom is not None or not xyz.requires_grad:
+            # coordinates are inputs in every reference model: the feature-independent half runs without autograd
+            new_xyz, idx, grouped_xyz = geom if geom is not None else self.geometry(xyz)
+            if points is not None and self.use_xyz:
                 # [xyz, features] rows written once, padded to a multiple of 4 columns (shared_mlp pads the weight)
                 new_points = group_concat(points, idx, grouped_xyz)
             elif points is not None:
-                grouped_points = group_point(points, idx)
-                new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if self.use_xyz else grouped_points
+                new_points = group_point(points, idx)
             else:
                 new_points = grouped_xyz
         else:
@@ -327,10 +327,10 @@ class PointnetSAFPStack(nn.Module):
 
 # ---------------------------------------------------------------- IoU / NMS adapters (hf/core/compute_iou.py)
 def boxes3d_to_bev(boxes3d):
-    """compute_iou.py:7-20: (N,7)[x,y,z,l,w,h,ry] -> (N,5)[x - l/2, z - w/2, x + l/2, z + w/2, ry]"""
-    cu, cv = boxes3d[:, 0], boxes3d[:, 2]
-    half_l, half_w = boxes3d[:, 3] / 2, boxes3d[:, 4] / 2
-    return torch.stack([cu - half_l, cv - half_w, cu + half_l, cv + half_w, boxes3d[:, 6]], dim=1)
+    """compute_iou.py:7-20: (...,7)[x,y,z,l,w,h,ry] -> (...,5)[x - l/2, z - w/2, x + l/2, z + w/2, ry]"""
+    cu, cv = boxes3d[..., 0], boxes3d[..., 2]
+    half_l, half_w = boxes3d[..., 3] / 2, boxes3d[..., 4] / 2
+    return torch.stack([cu - half_l, cv - half_w, cu + half_l, cv + half_w, boxes3d[..., 6]], dim=-1)
 
 
 def box3d_iou(boxes_a, boxes_b):

@@ -86,8 +86,7 @@ class TwoStageDetector(nn.Module):
         top_b = torch.gather(boxes, 1, top_i.unsqueeze(-1).expand(-1, -1, 7))
         # tf.map_fn(sb_nms_fn) over the frames (rpn_model.py:683-687) as ONE batched device NMS; the tail of each
         # keep row repeats keep[0] (bev_iou.cpp:110-112), which is what fixed_num_proposal_nms relies on
-        bev = torch.stack([modules.boxes3d_to_bev(top_b[b]) for b in range(top_b.shape[0])])
-        keep, _ = oriented_nms_batched(bev.contiguous(), self.rpn_nms_thresh)
+        keep, _ = oriented_nms_batched(modules.boxes3d_to_bev(top_b).contiguous(), self.rpn_nms_thresh)
         ind = keep[:, :self.rpn_nms_size].long()
         proposals = torch.gather(top_b, 1, ind.unsqueeze(-1).expand(-1, -1, 7))
         return feats, proposals, torch.gather(top_s, 1, ind), scores
@@ -108,12 +107,18 @@ class TwoStageDetector(nn.Module):
         _, f3, _ = self.rcnn_sa3(x2, f2)
         score, refined = self.rcnn_head(f3.squeeze(1), flat[:, 0:3])
         score = score * non_empty.float()                                   # empty RoIs carry no evidence
+        # model_util.py:101-142 / rcnn_model.py:731-778 for all frames at once: sort by score, ONE batched oriented
+        # NMS, drop the keep[0] padding (= keep the first `num` entries), one host read of the counts
+        score, refined = score.view(b, n_prop), refined.view(b, n_prop, 7)
+        order = torch.sort(score, dim=1, descending=True, stable=True).indices
+        bev = torch.gather(modules.boxes3d_to_bev(refined), 1, order.unsqueeze(-1).expand(-1, -1, 5))
+        keep, num = oriented_nms_batched(bev.contiguous(), self.rcnn_nms_thresh)
+        ind = torch.gather(order, 1, keep.long())
+        counts = torch.clamp(num, max=self.rcnn_nms_size).tolist()
         detections = []
-        for i in range(b):                                                  # rcnn_model.py:731-778
-            s, bx = score[i * n_prop:(i + 1) * n_prop], refined[i * n_prop:(i + 1) * n_prop]
-            ind, n = modules.sb_nms(bx, s, self.rcnn_nms_thresh, self.rcnn_nms_size, fixed_num_proposal_nms=False)
-            ind = ind[:n].long()
-            detections.append({"boxes": bx[ind], "scores": s[ind]})
+        for i in range(b):
+            sel = ind[i, :counts[i]]
+            detections.append({"boxes": refined[i, sel], "scores": score[i, sel]})
         return detections
 
     @torch.no_grad()

@@ -1095,6 +1095,20 @@ def test_shared_mlp_chain_node(hf, rows, pool_k, widths):
             big = max(float(want.abs().max()), 1.0)
             torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-2 * big)
             assert (got - want).abs().mean().item() <= 5e-4 * big
+    # inference: running statistics, MFMA forward with the normalisation applied on load where it pays
+    layers.eval()
+    for fc, bn in ref:
+        bn.eval()
+    with torch.no_grad():
+        e1 = x1.detach()
+        for fc, bn in ref:
+            e1 = torch.relu(bn(fc(e1)))
+        if pool_k:
+            e1 = e1.view(rows // pool_k, pool_k, -1).max(dim=1).values
+        before = [l.bn.running_mean.clone() for l in layers]
+        e2 = shared_mlp(layers, x2.detach(), pool_k)
+    torch.testing.assert_close(e2, e1, rtol=2e-4, atol=5e-5)
+    assert all(torch.equal(l.bn.running_mean, b) for l, b in zip(layers, before))  # inference leaves them alone
 
 
 @pytest.mark.parametrize("groups,k,cin,cout", [(4096, 32, 32, 64), (333, 17, 7, 5), (1024, 64, 128, 256), (50, 255, 16, 24)])
