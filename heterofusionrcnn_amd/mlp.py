@@ -10,6 +10,13 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 
+def _on_gpu(*tensors):
+    """every entry point below hands raw device pointers to HIP kernels: a host tensor must raise, not fault"""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("heterofusionrcnn_amd.mlp: tensors must live on the GPU (there is no CPU implementation)")
+
+
 def _workspace(rows, c, device):
     nbytes = _lib.lib().hf_bn_workspace(rows, c)
     return torch.empty((nbytes // 4,), dtype=torch.float32, device=device), nbytes
@@ -68,6 +75,7 @@ def linear_wgrad(grad_z, x, in_bn=None):
     """dW (Cout, Cin) = grad_z^T x on the fp32 MFMA kernel (csrc/gemm.hip): rows cut into chunks, partial tiles
     summed in a fixed order.  in_bn = (gamma, beta, mean, invstd) of the previous layer: x is then that layer's
     pre-BN output and relu(bn(x)) is applied while it is staged."""
+    _on_gpu(grad_z, x)
     rows, cout = grad_z.shape
     cin = x.shape[1]
     L = _lib.lib()
@@ -86,6 +94,7 @@ def linear_bn_fwd(x, weight, bias, bn, in_bn=None, keep_act=False, update_runnin
     in_bn = (gamma, beta, mean, invstd) of the previous layer: x is that layer's pre-BN output and relu(bn(x)) is
     applied on load; keep_act also stores that activated input (x_act, else None); update_running=False leaves the
     running estimates alone (inference: the returned batch statistics are then simply not used)."""
+    _on_gpu(x, weight, bias)
     rows, cin = x.shape
     cout = weight.shape[0]
     L = _lib.lib()
@@ -283,8 +292,9 @@ def shared_mlp(layers, x, pool_k=0):
     the max over each run of pool_k rows.  One fused node in training when every layer has BN+ReLU (each layer on
     the MFMA forward kernel where that pays, else library GEMM + statistics pass); otherwise layer by layer."""
     layers = list(layers)
+    _on_gpu(x)
     x = x.contiguous()
-    bn_relu = x.is_cuda and all(l.bn is not None and l.bn.relu for l in layers)
+    bn_relu = all(l.bn is not None and l.bn.relu for l in layers)
     pool_ok = pool_k == 0 or (pool_k <= 255 and x.shape[0] % pool_k == 0)
     fused = bn_relu and pool_ok and all(l.bn.training for l in layers)
     extra = x.shape[1] - layers[0].fc.in_features  # zero columns appended by the producer (grouping.group_concat)
@@ -351,6 +361,7 @@ class _LinearBNReLU(torch.autograd.Function):
 
 def linear_bn_relu(x, weight, bias, bn):
     """x (R, Cin) -> relu(bn(x W^T + b)) with `bn` a BatchNormReLU module (training mode: fused node)"""
+    _on_gpu(x, weight, bias)
     if bn.training:
         return _LinearBNReLU.apply(x.contiguous(), weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                    bn.eps, bn.momentum, bn.relu)
@@ -430,6 +441,7 @@ class _LinearBNReLUMaxPool(torch.autograd.Function):
 def linear_bn_relu_maxpool(x, weight, bias, bn, k):
     """x (G*K, Cin), K rows per group -> (G, Cout); `bn` a BatchNormReLU module with relu=True"""
     assert bn.relu and x.shape[0] % k == 0 and k <= 255
+    _on_gpu(x, weight, bias)
     x = x.contiguous()
     if bn.training:
         return _LinearBNReLUMaxPool.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,

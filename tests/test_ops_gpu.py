@@ -932,6 +932,37 @@ def test_two_stage_inference_flow(hf, oracle_mod):
         assert torch.equal(piped[j]["boxes"], alone["boxes"].cpu()) and torch.equal(piped[j]["scores"], alone["scores"].cpu())
 
 
+def test_mlp_entry_points_reject_bad_arguments(hf):
+    """argument checks of the caller-side entry points: HF_EINVAL -> ValueError, never a launch"""
+    import ctypes
+    from heterofusionrcnn_amd import _lib
+    from heterofusionrcnn_amd.mlp import BatchNormReLU, linear_bn_fwd, linear_wgrad
+    L = _lib.lib()
+    x = torch.randn(64, 8, device="cuda")
+    bn = BatchNormReLU(300).cuda()
+    with pytest.raises(ValueError):   # more output channels than the forward kernel holds accumulator tiles for
+        linear_bn_fwd(x, torch.randn(300, 8, device="cuda"), torch.zeros(300, device="cuda"), bn)
+    z = torch.empty(64, 4, device="cuda"); m = torch.empty(4, device="cuda")
+    ws = torch.empty(L.hf_linear_bn_fwd_workspace(4) // 4, device="cuda")
+    args = [64, 8, 4, _lib.ptr(x), None, None, None, None, _lib.ptr(torch.empty_like(x)), _lib.ptr(torch.randn(4, 8, device="cuda")),
+            None, _lib.ptr(z), 1e-3, 0.1, None, None, _lib.ptr(m), _lib.ptr(m.clone()), _lib.ptr(ws), ws.numel() * 4, None]
+    assert L.hf_linear_bn_fwd(*args) == _lib.HF_EINVAL          # x_act without an activation to apply
+    args[8] = None; args[19] = 16
+    assert L.hf_linear_bn_fwd(*args) == _lib.HF_EWORKSPACE      # workspace too small
+    assert L.hf_linear_bn_bwd(64, 4, 300, _lib.ptr(z), *([None] * 8), _lib.ptr(x), _lib.ptr(x), *([None] * 7), None, 0,
+                              None) == _lib.HF_EINVAL           # cin beyond the input-gradient kernel
+    assert L.hf_bn_stats(0, 4, _lib.ptr(z), 1e-3, 0.1, None, None, _lib.ptr(m), _lib.ptr(m), None, 0, None) == _lib.HF_EINVAL
+    from heterofusionrcnn_amd import modules
+    from heterofusionrcnn_amd.mlp import shared_mlp
+    with pytest.raises(RuntimeError):  # no CPU implementation anywhere on the path: host tensors raise
+        linear_wgrad(torch.randn(8, 4), torch.randn(8, 3))
+    with pytest.raises(RuntimeError):
+        shared_mlp([modules.SharedMLPLayer(3, 4)], torch.randn(8, 3))
+    with pytest.raises(RuntimeError):
+        modules.SharedMLPLayer(3, 4)(torch.randn(8, 3))
+    assert L.hf_linear_wgrad_workspace(0, 4, 4) == 0
+
+
 def test_batched_nms_equals_per_frame(hf, oracle_mod):
     rng = np.random.default_rng(8)
     frames = np.stack([_clustered(rng, 30, 10) for _ in range(3)])
