@@ -897,11 +897,10 @@ HF_API int hf_group_point_grad(int b, int n, int c, int m, int nsample, const fl
 HF_API int hf_group_concat(int b, int n, int c, int m, int nsample, int width, const float *grouped_xyz,
                            const float *points, const int *idx, float *out, hf_stream_t stream)
 {
-    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || width < 3 + c || width % 4 != 0 || !grouped_xyz || !points ||
-        !idx || !out || reinterpret_cast<uintptr_t>(out) % 16 != 0)
-        return HF_EINVAL;
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || width < 3 + c || width % 4 != 0) return HF_EINVAL;
     const long long nrows = static_cast<long long>(b) * m * nsample;
-    if (nrows == 0) return HF_OK;
+    if (nrows == 0) return HF_OK;  // empty tensors carry null pointers
+    if (!grouped_xyz || !points || !idx || !out || reinterpret_cast<uintptr_t>(out) % 16 != 0) return HF_EINVAL;
     const int block = 256;
     hipLaunchKernelGGL(group_concat_kernel, dim3(grid_for(nrows * (width / 4), block)), dim3(block), 0, as_stream(stream), n,
                        c, width / 4, static_cast<long long>(m) * nsample, nrows, grouped_xyz, points, idx, out);
@@ -911,14 +910,14 @@ HF_API int hf_group_concat(int b, int n, int c, int m, int nsample, int width, c
 HF_API int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int width, const float *grad_out, const int *idx,
                                 float *grad_points, hf_stream_t stream)
 {
-    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || width < 3 + c || !grad_out || !idx || !grad_points)
-        return HF_EINVAL;
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || width < 3 + c || !grad_points) return HF_EINVAL;
     if (b == 0) return HF_OK;
     hipStream_t st = as_stream(stream);
     int rc = hip_status(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(b) * n * c, st));
     if (rc != HF_OK) return rc;
     const long long nrows = static_cast<long long>(b) * m * nsample;
-    if (nrows == 0) return HF_OK;
+    if (nrows == 0) return HF_OK;  // empty tensors carry null pointers
+    if (!grad_out || !idx) return HF_EINVAL;
     const int block = 256;
     hipLaunchKernelGGL(group_concat_grad_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c, width,
                        static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);

@@ -576,11 +576,10 @@ HF_API int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const
 HF_API int hf_three_interpolate_concat(int b, int m, int c, int n, int c1, int width, const float *points, const int *idx,
                                        const float *weight, const float *skip, float *out, hf_stream_t stream)
 {
-    if (b < 0 || c <= 0 || m <= 0 || n < 0 || c1 < 0 || width < c + c1 || width % 4 != 0 || !points || !idx || !weight ||
-        !out || (c1 > 0 && !skip) || reinterpret_cast<uintptr_t>(out) % 16 != 0)
-        return HF_EINVAL;
+    if (b < 0 || c <= 0 || m <= 0 || n < 0 || c1 < 0 || width < c + c1 || width % 4 != 0) return HF_EINVAL;
     const long long nrows = static_cast<long long>(b) * n;
-    if (nrows == 0) return HF_OK;
+    if (nrows == 0) return HF_OK;  // empty tensors carry null pointers
+    if (!points || !idx || !weight || !out || (c1 > 0 && !skip) || reinterpret_cast<uintptr_t>(out) % 16 != 0) return HF_EINVAL;
     const int block = 256;
     const dim3 grid(grid_for(nrows * (width / 4), block));
     const bool vec4 = c % 4 == 0 && reinterpret_cast<uintptr_t>(points) % 16 == 0;

@@ -932,6 +932,47 @@ def test_two_stage_inference_flow(hf, oracle_mod):
         assert torch.equal(piped[j]["boxes"], alone["boxes"].cpu()) and torch.equal(piped[j]["scores"], alone["scores"].cpu())
 
 
+def test_caller_side_ops_on_empty_and_ragged_shapes(hf, oracle_mod):
+    """zero-size and non-tile-multiple shapes through the entry points added for the SA/FP callers"""
+    from heterofusionrcnn_amd import modules
+    from heterofusionrcnn_amd.grouping import group_concat
+    from heterofusionrcnn_amd.interpolate import three_interpolate_concat, three_nn_inverse
+    from heterofusionrcnn_amd.mlp import linear_bn_fwd, linear_wgrad, shared_mlp, BatchNormReLU
+    # no queries: an empty (b, 0, k, width) result and a zero gradient
+    pts = torch.randn(2, 50, 6, device="cuda", requires_grad=True)
+    out = group_concat(pts, torch.zeros((2, 0, 4), dtype=torch.int32, device="cuda"), torch.zeros((2, 0, 4, 3), device="cuda"))
+    assert out.shape == (2, 0, 4, 12)
+    out.sum().backward()
+    assert torch.equal(pts.grad, torch.zeros_like(pts))
+    # no unknown points: empty interpolation, empty inverse, zero gradient
+    idx0 = torch.zeros((2, 0, 3), dtype=torch.int32, device="cuda")
+    off, ent = three_nn_inverse(idx0, 7)
+    assert off.shape == (2, 8) and not off.any() and ent.shape == (2, 0)
+    p2 = torch.randn(2, 7, 8, device="cuda", requires_grad=True)
+    o = three_interpolate_concat(p2, None, idx0, torch.zeros((2, 0, 3), device="cuda"), (off, ent))
+    assert o.shape == (2, 0, 8)
+    o.sum().backward()
+    assert torch.equal(p2.grad, torch.zeros_like(p2))
+    # three_nn with fewer than three known points, one unknown point
+    d, i = hf.three_nn(dev(np.zeros((1, 1, 3), np.float32)), dev(np.ones((1, 2, 3), np.float32)))
+    od, oi = oracle_mod.three_nn(np.zeros((1, 1, 3), np.float32), np.ones((1, 2, 3), np.float32))
+    assert np.array_equal(host(i), oi) and np.array_equal(host(d), od)
+    # MFMA kernels on shapes that are not multiples of any tile: 1 row, 129 rows, odd channel counts
+    for rows, cin, cout in [(1, 3, 2), (129, 33, 65), (257, 130, 31)]:
+        x = torch.randn(rows, cin, device="cuda"); w = torch.randn(cout, cin, device="cuda"); b = torch.randn(cout, device="cuda")
+        bn = BatchNormReLU(cout).cuda()
+        z, mean, invstd, _ = linear_bn_fwd(x, w, b, bn)
+        ref = x.double() @ w.double().t() + b.double()
+        torch.testing.assert_close(z.double(), ref, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(mean.double(), ref.mean(0), rtol=1e-5, atol=1e-5)
+        g = torch.randn(rows, cout, device="cuda")
+        torch.testing.assert_close(linear_wgrad(g, x).double(), g.double().t() @ x.double(), rtol=1e-5, atol=1e-4)
+    # a one-row shared MLP (batch statistics of a single row: variance 0) stays finite
+    layers = torch.nn.ModuleList([modules.SharedMLPLayer(3, 4), modules.SharedMLPLayer(4, 5)]).cuda()
+    y = shared_mlp(layers, torch.randn(1, 3, device="cuda"))
+    assert y.shape == (1, 5) and torch.isfinite(y).all()
+
+
 def test_mlp_entry_points_reject_bad_arguments(hf):
     """argument checks of the caller-side entry points: HF_EINVAL -> ValueError, never a launch"""
     import ctypes
