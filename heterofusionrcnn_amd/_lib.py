@@ -68,6 +68,10 @@ _SIGNATURES = {
     "hf_bn_relu_bwd_dx": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "hf_linear_bn_bwd_workspace": [_i],
     "hf_linear_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 18 + [_vp, _sz, _vp],
+    "hf_project_gather": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hf_project_gather_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "hf_bin_box_decode": [ctypes.c_longlong, _i] + [_vp] * 13 + [_f, _f, _vp, _vp],
+    "hf_bin_box_encode": [ctypes.c_longlong, _i, _i] + [_vp] * 7 + [_f, _f, _f, _f] + [_vp] * 8 + [_vp],
     "hf_version": [],
     "hf_strerror": [_i],
     "hf_last_hip_error": [],

@@ -1,0 +1,249 @@
+// glue.hip -- the element-wise / gather steps either side of the custom ops for gfx950.
+//
+//   project_gather   the LiDAR -> image fusion step: hf/core/projection.py:5-32 (tf_rect_to_image) +
+//                    hf/core/models/rpn_model.py:227-235 (int cast, tf.gather_nd of the image feature map).  One
+//                    pass: the (B,P,2) pixel tensor, its int cast, the (B,P,3) index tensor and the gather become
+//                    one kernel that reads 12 B of coordinates and C floats of features per point.
+//   bin_box_decode / bin_box_encode   hf/core/bin_based_box3d_encoder.py:9-269: ~20 TensorFlow ops (tile, stack,
+//                    2x2 matmul, mod, where, clip, floor ...) per call as one element-wise kernel each.
+// Arithmetic: fp32, no contraction, expressions in the order the oracle (oracle/hf_oracle.c) writes them.
+#include <math.h>
+
+#include "hf_common.h"
+
+namespace hf {
+
+struct Pix { int u, v; };
+
+__device__ __forceinline__ Pix project_point(const float *__restrict__ P, float x, float y, float z)
+{
+    const float uh = P[0] * x + P[1] * y + P[2] * z + P[3];
+    const float vh = P[4] * x + P[5] * y + P[6] * z + P[7];
+    const float d = P[8] * x + P[9] * y + P[10] * z + P[11];
+    const float uf = uh / d, vf = vh / d;
+    const bool ok = uf > -2147483648.0f && uf < 2147483648.0f && vf > -2147483648.0f && vf < 2147483648.0f;
+    Pix r;
+    r.u = ok ? static_cast<int>(uf) : -1;  // truncation toward zero, as tf.cast
+    r.v = ok ? static_cast<int>(vf) : -1;
+    return r;
+}
+
+// c/VEC lanes per point; every lane recomputes the 12-flop projection of its point
+template <int VEC>
+__global__ void project_gather_kernel(int p, int h, int w, int c, long long nrows, const float *__restrict__ pts,
+                                      const float *__restrict__ calib, const float *__restrict__ img,
+                                      float *__restrict__ out, int *__restrict__ pix)
+{
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int cv = c / VEC;
+    const long long total = nrows * cv;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / cv;
+        const int l = static_cast<int>(e - row * cv);
+        const long long bb = row / p;
+        const float *x = pts + row * 3;
+        const Pix q = project_point(calib + bb * 12, x[0], x[1], x[2]);
+        if (pix && l == 0) { pix[row * 2] = q.u; pix[row * 2 + 1] = q.v; }
+        vec_t v;
+        if (q.u >= 0 && q.u < w && q.v >= 0 && q.v < h) {
+            v = *reinterpret_cast<const vec_t *>(img + ((bb * h + q.v) * w + q.u) * c + l * VEC);
+        } else {
+            if constexpr (VEC == 1) v = 0.0f; else v = vec_t{ 0.f, 0.f, 0.f, 0.f };
+        }
+        *reinterpret_cast<vec_t *>(out + row * c + l * VEC) = v;
+    }
+}
+
+__global__ void project_gather_grad_kernel(int p, int h, int w, int c, long long nrows,
+                                           const float *__restrict__ grad_out, const int *__restrict__ pix,
+                                           float *__restrict__ grad_img)
+{
+    const long long total = nrows * c;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / c;
+        const int l = static_cast<int>(e - row * c);
+        const long long bb = row / p;
+        const int u = pix[row * 2], v = pix[row * 2 + 1];
+        if (u < 0 || u >= w || v < 0 || v >= h) continue;
+        atomicAdd(grad_img + ((bb * h + v) * w + u) * c + l, grad_out[e]);
+    }
+}
+
+__global__ void bin_box_decode_kernel(long long rows, int k, const float *__restrict__ ref_pts,
+                                      const float *__restrict__ ref_theta, const int *__restrict__ bin_x,
+                                      const float *__restrict__ res_x_norm, const int *__restrict__ bin_z,
+                                      const float *__restrict__ res_z_norm, const int *__restrict__ bin_theta,
+                                      const float *__restrict__ res_theta_norm, const float *__restrict__ res_y,
+                                      const float *__restrict__ res_size_norm, const float *__restrict__ mean_sizes,
+                                      const float *__restrict__ ss, const float *__restrict__ deltas, float r,
+                                      float delta_theta, float *__restrict__ boxes)
+{
+    const long long total = rows * k;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long i = e / k;
+        const int j = static_cast<int>(e - i * k);
+        const float th0 = ref_theta ? ref_theta[i] : 0.0f;
+        float dx = (static_cast<float>(bin_x[e]) + 0.5f) * deltas[j] - ss[j] + res_x_norm[e] * deltas[j];
+        float dz = (static_cast<float>(bin_z[e]) + 0.5f) * deltas[j] - ss[j] + res_z_norm[e] * deltas[j];
+        if (ref_theta) {
+            const float sn = sinf(th0), cs = cosf(th0);
+            const float rx = cs * dx + sn * dz, rz = -sn * dx + cs * dz;
+            dx = rx; dz = rz;
+        }
+        float *o = boxes + e * 7;
+        o[0] = dx + ref_pts[i * 3 + 0];
+        o[1] = res_y[e] + ref_pts[i * 3 + 1];
+        o[2] = dz + ref_pts[i * 3 + 2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[3 + d] = mean_sizes[e * 3 + d] + res_size_norm[e * 3 + d] * mean_sizes[e * 3 + d];
+        o[6] = th0 + (static_cast<float>(bin_theta[e]) + 0.5f) * delta_theta - r + res_theta_norm[e] * 0.5f * delta_theta;
+    }
+}
+
+__device__ __forceinline__ float floormodf(float x, float y)
+{
+    float r = fmodf(x, y);
+    if (r != 0.0f && ((y < 0.0f) != (r < 0.0f))) r += y;
+    return r;
+}
+
+__global__ void bin_box_encode_kernel(long long rows, int k, int rcnn, const float *__restrict__ ref_pts,
+                                      const float *__restrict__ ref_theta, const float *__restrict__ boxes,
+                                      const float *__restrict__ mean_sizes, const float *__restrict__ ss,
+                                      const float *__restrict__ deltas, const float *__restrict__ hi_xz, float r,
+                                      float hi_theta, float delta_theta, float half_delta_theta,
+                                      int *__restrict__ bin_x, float *__restrict__ res_x_norm, int *__restrict__ bin_z,
+                                      float *__restrict__ res_z_norm, int *__restrict__ bin_theta,
+                                      float *__restrict__ res_theta_norm, float *__restrict__ res_y,
+                                      float *__restrict__ res_size_norm)
+{
+    const float two_pi = static_cast<float>(2.0 * 3.141592653589793), pi = static_cast<float>(3.141592653589793);
+    const float half_pi = static_cast<float>(0.5 * 3.141592653589793);
+    const float three_half_pi = static_cast<float>(1.5 * 3.141592653589793);
+    for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < rows;
+         i += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const float *bx = boxes + i * 7;
+        float dx = bx[0] - ref_pts[i * 3 + 0];
+        const float dy = bx[1] - ref_pts[i * 3 + 1];
+        float dz = bx[2] - ref_pts[i * 3 + 2];
+        const float th0 = ref_theta ? ref_theta[i] : 0.0f;
+        if (ref_theta) {
+            const float a = th0 * -1.0f;
+            const float sn = sinf(a), cs = cosf(a);
+            const float rx = cs * dx + sn * dz, rz = -sn * dx + cs * dz;
+            dx = rx; dz = rz;
+        }
+        float dshift;
+        if (!rcnn) {
+            const float dtheta = bx[6] - th0;
+            dshift = fminf(fmaxf(dtheta + r, 0.0f), hi_theta);
+        } else {
+            float dtheta = bx[6] - floormodf(th0, two_pi);
+            dtheta = floormodf(dtheta, two_pi);
+            if (dtheta > half_pi && dtheta < three_half_pi) dtheta = floormodf(dtheta + pi, two_pi);
+            dshift = floormodf(dtheta + half_pi, two_pi);
+            dshift = fminf(fmaxf(dshift - r, 1e-3f), hi_theta);
+        }
+        for (int j = 0; j < k; ++j) {
+            const long long e = i * k + j;
+            const float xs = fminf(fmaxf(dx + ss[j], 0.0f), hi_xz[j]);
+            const float fx = floorf(xs / deltas[j]);
+            bin_x[e] = static_cast<int>(fx);
+            res_x_norm[e] = (xs - (fx + 0.5f) * deltas[j]) / deltas[j];
+            const float zs = fminf(fmaxf(dz + ss[j], 0.0f), hi_xz[j]);
+            const float fz = floorf(zs / deltas[j]);
+            bin_z[e] = static_cast<int>(fz);
+            res_z_norm[e] = (zs - (fz + 0.5f) * deltas[j]) / deltas[j];
+        }
+        const float ft = floorf(dshift / delta_theta);
+        bin_theta[i] = static_cast<int>(ft);
+        res_theta_norm[i] = (dshift - (ft + 0.5f) * delta_theta) / half_delta_theta;
+        res_y[i] = dy;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) res_size_norm[i * 3 + d] = (bx[3 + d] - mean_sizes[i * 3 + d]) / mean_sizes[i * 3 + d];
+    }
+}
+
+static int glue_grid(long long items, int block)
+{
+    long long g = (items + block - 1) / block;
+    const long long cap = static_cast<long long>(kNumCU) * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return static_cast<int>(g);
+}
+
+}  // namespace hf
+
+using namespace hf;
+
+HF_API int hf_project_gather(int b, int p, int h, int w, int c, const float *pts, const float *calib, const float *img,
+                             float *out, int *pix, hf_stream_t stream)
+{
+    if (b < 0 || p < 0 || h <= 0 || w <= 0 || c <= 0) return HF_EINVAL;
+    const long long nrows = static_cast<long long>(b) * p;
+    if (nrows == 0) return HF_OK;  // empty tensors carry null pointers
+    if (!pts || !calib || !img || !out) return HF_EINVAL;
+    const bool vec4 = c % 4 == 0 && (reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
+    if (vec4)
+        hipLaunchKernelGGL((project_gather_kernel<4>), dim3(glue_grid(nrows * (c / 4), 256)), dim3(256), 0, as_stream(stream),
+                           p, h, w, c, nrows, pts, calib, img, out, pix);
+    else
+        hipLaunchKernelGGL((project_gather_kernel<1>), dim3(glue_grid(nrows * c, 256)), dim3(256), 0, as_stream(stream), p,
+                           h, w, c, nrows, pts, calib, img, out, pix);
+    return launch_status();
+}
+
+HF_API int hf_project_gather_grad(int b, int p, int h, int w, int c, const float *grad_out, const int *pix,
+                                  float *grad_img, hf_stream_t stream)
+{
+    if (b < 0 || p < 0 || h <= 0 || w <= 0 || c <= 0 || (b > 0 && !grad_img)) return HF_EINVAL;
+    if (b == 0) return HF_OK;
+    hipStream_t st = as_stream(stream);
+    int rc = hip_status(hipMemsetAsync(grad_img, 0, sizeof(float) * static_cast<size_t>(b) * h * w * c, st));
+    if (rc != HF_OK) return rc;
+    const long long nrows = static_cast<long long>(b) * p;
+    if (nrows == 0) return HF_OK;
+    if (!grad_out || !pix) return HF_EINVAL;
+    hipLaunchKernelGGL(project_gather_grad_kernel, dim3(glue_grid(nrows * c, 256)), dim3(256), 0, st, p, h, w, c, nrows,
+                       grad_out, pix, grad_img);
+    return launch_status();
+}
+
+HF_API int hf_bin_box_decode(long long rows, int k, const float *ref_pts, const float *ref_theta, const int *bin_x,
+                             const float *res_x_norm, const int *bin_z, const float *res_z_norm, const int *bin_theta,
+                             const float *res_theta_norm, const float *res_y, const float *res_size_norm,
+                             const float *mean_sizes, const float *ss, const float *deltas, float r, float delta_theta,
+                             float *boxes, hf_stream_t stream)
+{
+    if (rows < 0 || k <= 0) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    if (!ref_pts || !bin_x || !res_x_norm || !bin_z || !res_z_norm || !bin_theta || !res_theta_norm || !res_y ||
+        !res_size_norm || !mean_sizes || !ss || !deltas || !boxes)
+        return HF_EINVAL;
+    hipLaunchKernelGGL(bin_box_decode_kernel, dim3(glue_grid(rows * k, 256)), dim3(256), 0, as_stream(stream), rows, k,
+                       ref_pts, ref_theta, bin_x, res_x_norm, bin_z, res_z_norm, bin_theta, res_theta_norm, res_y,
+                       res_size_norm, mean_sizes, ss, deltas, r, delta_theta, boxes);
+    return launch_status();
+}
+
+HF_API int hf_bin_box_encode(long long rows, int k, int rcnn, const float *ref_pts, const float *ref_theta,
+                             const float *boxes, const float *mean_sizes, const float *ss, const float *deltas,
+                             const float *hi_xz, float r, float hi_theta, float delta_theta, float half_delta_theta,
+                             int *bin_x, float *res_x_norm, int *bin_z, float *res_z_norm, int *bin_theta,
+                             float *res_theta_norm, float *res_y, float *res_size_norm, hf_stream_t stream)
+{
+    if (rows < 0 || k <= 0) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    if (!ref_pts || !boxes || !mean_sizes || !ss || !deltas || !hi_xz || !bin_x || !res_x_norm || !bin_z || !res_z_norm ||
+        !bin_theta || !res_theta_norm || !res_y || !res_size_norm)
+        return HF_EINVAL;
+    hipLaunchKernelGGL(bin_box_encode_kernel, dim3(glue_grid(rows, 256)), dim3(256), 0, as_stream(stream), rows, k, rcnn,
+                       ref_pts, ref_theta, boxes, mean_sizes, ss, deltas, hi_xz, r, hi_theta, delta_theta,
+                       half_delta_theta, bin_x, res_x_norm, bin_z, res_z_norm, bin_theta, res_theta_norm, res_y,
+                       res_size_norm);
+    return launch_status();
+}

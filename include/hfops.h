@@ -292,6 +292,33 @@ int hf_linear_bn_bwd(long long rows, int cout, int cin, const float *dy_or_dz, c
                      const float *p_beta, const float *p_mean, const float *p_invstd, float *p_dgamma, float *p_dbeta,
                      void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* ---- glue either side of the ops ---- */
+
+/* The LiDAR -> image fusion step in one pass: hf/core/projection.py:5-32 (tf_rect_to_image: homogeneous point times
+ * the 3x4 P2 matrix, divide by depth) + hf/core/models/rpn_model.py:227-235 (tf.cast to int32, tf.gather_nd of the
+ * image feature map at [b, v, u]).  pts (b,p,3), calib (b,3,4), img (b,h,w,c) -> out (b,p,c); a pixel outside the
+ * image gives zeros (tf.gather_nd on GPU).  pix (b,p,2) [u,v], optional, is what the gradient needs.
+ * hf_project_gather_grad: grad_img (b,h,w,c), zero-filled here, += grad_out rows at their pixels. */
+int hf_project_gather(int b, int p, int h, int w, int c, const float *pts, const float *calib, const float *img, float *out,
+                      int *pix, hf_stream_t stream);
+int hf_project_gather_grad(int b, int p, int h, int w, int c, const float *grad_out, const int *pix, float *grad_img,
+                           hf_stream_t stream);
+/* hf/core/bin_based_box3d_encoder.py:9-139 (tf_decode) for `rows` reference points x k classes: rows = B*p in the RPN
+ * (ref_theta NULL = the constant 0), the RoI count in the RCNN.  Per (row, class) inputs are (rows, k[, 3]) arrays;
+ * ss / deltas (k,) the per-class XZ search range and bin length; boxes (rows, k, 7) = [x, y, z, l, w, h, ry]. */
+int hf_bin_box_decode(long long rows, int k, const float *ref_pts, const float *ref_theta, const int *bin_x,
+                      const float *res_x_norm, const int *bin_z, const float *res_z_norm, const int *bin_theta,
+                      const float *res_theta_norm, const float *res_y, const float *res_size_norm, const float *mean_sizes,
+                      const float *ss, const float *deltas, float r, float delta_theta, float *boxes, hf_stream_t stream);
+/* bin_based_box3d_encoder.py:142-269 (tf_encode); rcnn = 0 / 1 selects the rank-3 (RPN) / rank-2 (RCNN) orientation
+ * rule.  hi_xz (k,) = float32(2*Ss - 1e-3), hi_theta = float32(2*R - 1e-3), half_delta_theta = float32(0.5*DELTA_THETA):
+ * constants the reference forms in Python doubles before TensorFlow casts them. */
+int hf_bin_box_encode(long long rows, int k, int rcnn, const float *ref_pts, const float *ref_theta, const float *boxes,
+                      const float *mean_sizes, const float *ss, const float *deltas, const float *hi_xz, float r,
+                      float hi_theta, float delta_theta, float half_delta_theta, int *bin_x, float *res_x_norm, int *bin_z,
+                      float *res_z_norm, int *bin_theta, float *res_theta_norm, float *res_y, float *res_size_norm,
+                      hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -320,3 +320,53 @@ def ref_three_interpolate_grad(points_shape, idx, weight, grad_out):
     g = np.zeros((b, m, c), np.float32)
     getattr(ref_lib("itp"), _REF_ITP_GRAD)(b, n, c, m, _p(grad_out), _p(idx), _p(weight), _p(g))
     return g
+
+
+# ---- fusion gather and the bin-based box codec ----
+def project_gather(pts, calib, img):
+    pts, calib, img = _f(pts), _f(calib), _f(img)
+    b, p, _ = pts.shape
+    _, h, w, c = img.shape
+    out = np.empty((b, p, c), np.float32)
+    pix = np.empty((b, p, 2), np.int32)
+    lib().hfo_project_gather(b, p, h, w, c, _p(pts), _p(calib), _p(img), _p(out), _p(pix))
+    return out, pix
+
+
+def project_gather_grad(img_shape, pix, grad_out):
+    pix, grad_out = _i(pix), _f(grad_out)
+    b, h, w, c = img_shape
+    g = np.empty((b, h, w, c), np.float32)
+    lib().hfo_project_gather_grad(b, pix.shape[1], h, w, c, _p(grad_out), _p(pix), _p(g))
+    return g
+
+
+def bin_box_decode(ref_pts, ref_theta, bin_x, res_x_norm, bin_z, res_z_norm, bin_theta, res_theta_norm, res_y,
+                   res_size_norm, mean_sizes, ss, deltas, r, delta_theta):
+    """flattened form: ref_pts (rows,3), per (row, class) arrays (rows,k[,3]); ref_theta (rows,) or None"""
+    rows, k = bin_x.shape
+    boxes = np.empty((rows, k, 7), np.float32)
+    th = _f(ref_theta) if ref_theta is not None else None
+    lib().hfo_bin_box_decode(ctypes.c_longlong(rows), k, _p(_f(ref_pts)), _p(th) if th is not None else None, _p(_i(bin_x)),
+                             _p(_f(res_x_norm)), _p(_i(bin_z)), _p(_f(res_z_norm)), _p(_i(bin_theta)),
+                             _p(_f(res_theta_norm)), _p(_f(res_y)), _p(_f(res_size_norm)), _p(_f(mean_sizes)),
+                             _p(_f(np.asarray(ss, np.float64).astype(np.float32))),
+                             _p(_f(np.asarray(deltas, np.float64).astype(np.float32))), ctypes.c_float(np.float32(r)),
+                             ctypes.c_float(np.float32(delta_theta)), _p(boxes))
+    return boxes
+
+
+def bin_box_encode(ref_pts, ref_theta, boxes, mean_sizes, ss, deltas, r, delta_theta, k, rcnn):
+    rows = ref_pts.shape[0]
+    ss64, d64 = np.asarray(ss, np.float64), np.asarray(deltas, np.float64)
+    outs = [np.empty((rows, k), np.int32), np.empty((rows, k), np.float32), np.empty((rows, k), np.int32),
+            np.empty((rows, k), np.float32), np.empty((rows,), np.int32), np.empty((rows,), np.float32),
+            np.empty((rows,), np.float32), np.empty((rows, 3), np.float32)]
+    th = _f(ref_theta) if ref_theta is not None else None
+    lib().hfo_bin_box_encode(ctypes.c_longlong(rows), k, int(rcnn), _p(_f(ref_pts)), _p(th) if th is not None else None,
+                             _p(_f(boxes)), _p(_f(mean_sizes)), _p(_f(ss64.astype(np.float32))),
+                             _p(_f(d64.astype(np.float32))), _p(_f((2.0 * ss64 - 1e-3).astype(np.float32))),
+                             ctypes.c_float(np.float32(r)), ctypes.c_float(np.float32(2.0 * float(r) - 1e-3)),
+                             ctypes.c_float(np.float32(delta_theta)), ctypes.c_float(np.float32(0.5 * float(delta_theta))),
+                             *[_p(o) for o in outs])
+    return tuple(outs)

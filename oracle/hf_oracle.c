@@ -612,3 +612,148 @@ HFO_API void hfo_pc_crop_and_sample_grad_fts(const int *box_ind, const int *crop
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * glue either side of the ops.
+ *
+ * hfo_project_gather -- the LiDAR->image fusion step, hf/core/projection.py:5-32 (tf_rect_to_image) followed by
+ * hf/core/models/rpn_model.py:227-235: homogeneous point times the 3x4 P2 matrix, divide by depth, tf.cast to int32
+ * (truncation toward zero), tf.gather_nd(img_fts, [b, v, u]).  The matmul's 4-term sums are evaluated left to
+ * right (TensorFlow's order inside a 4-long dot product is not specified: parity unpinned there); an index outside
+ * the image yields zeros, which is tf.gather_nd's documented behaviour on GPU.  pix receives [u, v] per point.
+ * ------------------------------------------------------------------------------------------ */
+HFO_API void hfo_project_gather(int b, int p, int h, int w, int c, const float *pts, const float *calib,
+                                const float *img, float *out, int *pix)
+{
+    for (int i = 0; i < b; ++i) {
+        const float *P = calib + (size_t)i * 12;
+        for (int j = 0; j < p; ++j) {
+            const float *x = pts + ((size_t)i * p + j) * 3;
+            const float uh = P[0] * x[0] + P[1] * x[1] + P[2] * x[2] + P[3];
+            const float vh = P[4] * x[0] + P[5] * x[1] + P[6] * x[2] + P[7];
+            const float d = P[8] * x[0] + P[9] * x[1] + P[10] * x[2] + P[11];
+            const float uf = uh / d, vf = vh / d;
+            /* a float outside the int32 range (or NaN) has no defined cast: treated as outside the image */
+            const int ok = uf > -2147483648.0f && uf < 2147483648.0f && vf > -2147483648.0f && vf < 2147483648.0f;
+            const int u = ok ? (int)uf : -1, v = ok ? (int)vf : -1;
+            if (pix) { pix[((size_t)i * p + j) * 2] = u; pix[((size_t)i * p + j) * 2 + 1] = v; }
+            float *o = out + ((size_t)i * p + j) * c;
+            if (u >= 0 && u < w && v >= 0 && v < h) {
+                const float *s = img + (((size_t)i * h + v) * w + u) * c;
+                for (int l = 0; l < c; ++l) o[l] = s[l];
+            } else {
+                for (int l = 0; l < c; ++l) o[l] = 0.0f;
+            }
+        }
+    }
+}
+
+/* gradient w.r.t. the image features: rows scattered back in ascending point order */
+HFO_API void hfo_project_gather_grad(int b, int p, int h, int w, int c, const float *grad_out, const int *pix,
+                                     float *grad_img)
+{
+    memset(grad_img, 0, sizeof(float) * (size_t)b * h * w * c);
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < p; ++j) {
+            const int u = pix[((size_t)i * p + j) * 2], v = pix[((size_t)i * p + j) * 2 + 1];
+            if (u < 0 || u >= w || v < 0 || v >= h) continue;
+            float *g = grad_img + (((size_t)i * h + v) * w + u) * c;
+            const float *s = grad_out + ((size_t)i * p + j) * c;
+            for (int l = 0; l < c; ++l) g[l] += s[l];
+        }
+}
+
+/* tf.mod on floats = floored modulo (result takes the sign of the divisor) */
+static float hfo_floormodf(float x, float y)
+{
+    float r = fmodf(x, y);
+    if (r != 0.0f && ((y < 0.0f) != (r < 0.0f))) r += y;
+    return r;
+}
+
+/* hfo_bin_box_decode -- hf/core/bin_based_box3d_encoder.py:9-139 (tf_decode), both ranks at once: `rows` = B*p (RPN) or
+ * the number of RoIs (RCNN), k classes per row.  ref_theta may be NULL (the RPN passes the constant 0: no rotation).
+ * ss / deltas are the per-class search range and bin length (float32 of the config's doubles), r / delta_theta the
+ * orientation range and bin length.  rot = [[c, -s], [s, c]]; matmul(rot, [dx dz], transpose_a, transpose_b) gives
+ * dx' = c*dx + s*dz, dz' = -s*dx + c*dz (:58-79).  boxes (rows, k, 7) = [x, y, z, l, w, h, ry]. */
+HFO_API void hfo_bin_box_decode(long long rows, int k, const float *ref_pts, const float *ref_theta, const int *bin_x,
+                                const float *res_x_norm, const int *bin_z, const float *res_z_norm,
+                                const int *bin_theta, const float *res_theta_norm, const float *res_y,
+                                const float *res_size_norm, const float *mean_sizes, const float *ss,
+                                const float *deltas, float r, float delta_theta, float *boxes)
+{
+    for (long long i = 0; i < rows; ++i) {
+        const float th0 = ref_theta ? ref_theta[i] : 0.0f;
+        const float sn = ref_theta ? sinf(th0) : 0.0f, cs = ref_theta ? cosf(th0) : 1.0f;
+        for (int j = 0; j < k; ++j) {
+            const size_t e = (size_t)i * k + j;
+            float dx = ((float)bin_x[e] + 0.5f) * deltas[j] - ss[j] + res_x_norm[e] * deltas[j];
+            float dz = ((float)bin_z[e] + 0.5f) * deltas[j] - ss[j] + res_z_norm[e] * deltas[j];
+            if (ref_theta) {
+                const float rx = cs * dx + sn * dz, rz = -sn * dx + cs * dz;
+                dx = rx; dz = rz;
+            }
+            float *o = boxes + e * 7;
+            o[0] = dx + ref_pts[i * 3 + 0];
+            o[1] = res_y[e] + ref_pts[i * 3 + 1];
+            o[2] = dz + ref_pts[i * 3 + 2];
+            for (int d = 0; d < 3; ++d) o[3 + d] = mean_sizes[e * 3 + d] + res_size_norm[e * 3 + d] * mean_sizes[e * 3 + d];
+            o[6] = th0 + ((float)bin_theta[e] + 0.5f) * delta_theta - r + res_theta_norm[e] * 0.5f * delta_theta;
+        }
+    }
+}
+
+/* hfo_bin_box_encode -- bin_based_box3d_encoder.py:142-269 (tf_encode).  rcnn = 0: the RPN rank (dtheta = ry - ref_theta,
+ * clipped to [0, 2R - 1e-3] after the +R shift); rcnn = 1: the RCNN rank (orientation folded into (-pi/2, pi/2] around
+ * the proposal's, :235-246).  Outputs: bin_x/res_x_norm/bin_z/res_z_norm (rows, k); bin_theta/res_theta_norm/res_y
+ * (rows); res_size_norm (rows, 3).  Python computes 2*Ss - 1e-3, 2*R - 1e-3, 0.5*DELTA_THETA in double and TF casts
+ * the result to float32: the `hi_*` arguments carry those already-rounded constants. */
+HFO_API void hfo_bin_box_encode(long long rows, int k, int rcnn, const float *ref_pts, const float *ref_theta,
+                                const float *boxes, const float *mean_sizes, const float *ss, const float *deltas,
+                                const float *hi_xz, float r, float hi_theta, float delta_theta, float half_delta_theta,
+                                int *bin_x, float *res_x_norm, int *bin_z, float *res_z_norm, int *bin_theta,
+                                float *res_theta_norm, float *res_y, float *res_size_norm)
+{
+    const float two_pi = (float)(2.0 * 3.141592653589793), pi = (float)3.141592653589793;
+    const float half_pi = (float)(0.5 * 3.141592653589793), three_half_pi = (float)(1.5 * 3.141592653589793);
+    for (long long i = 0; i < rows; ++i) {
+        const float *bx = boxes + i * 7;
+        float dx = bx[0] - ref_pts[i * 3 + 0];
+        const float dy = bx[1] - ref_pts[i * 3 + 1];
+        float dz = bx[2] - ref_pts[i * 3 + 2];
+        const float th0 = ref_theta ? ref_theta[i] : 0.0f;
+        if (ref_theta) {
+            const float a = th0 * -1.0f;
+            const float sn = sinf(a), cs = cosf(a);
+            const float rx = cs * dx + sn * dz, rz = -sn * dx + cs * dz;
+            dx = rx; dz = rz;
+        }
+        float dshift;
+        if (!rcnn) {
+            const float dtheta = bx[6] - th0;
+            dshift = fminf(fmaxf(dtheta + r, 0.0f), hi_theta);
+        } else {
+            float dtheta = bx[6] - hfo_floormodf(th0, two_pi);
+            dtheta = hfo_floormodf(dtheta, two_pi);
+            if (dtheta > half_pi && dtheta < three_half_pi) dtheta = hfo_floormodf(dtheta + pi, two_pi);
+            dshift = hfo_floormodf(dtheta + half_pi, two_pi);
+            dshift = fminf(fmaxf(dshift - r, 1e-3f), hi_theta);
+        }
+        for (int j = 0; j < k; ++j) {
+            const size_t e = (size_t)i * k + j;
+            const float xs = fminf(fmaxf(dx + ss[j], 0.0f), hi_xz[j]);
+            const float fx = floorf(xs / deltas[j]);
+            bin_x[e] = (int)fx;
+            res_x_norm[e] = (xs - (fx + 0.5f) * deltas[j]) / deltas[j];
+            const float zs = fminf(fmaxf(dz + ss[j], 0.0f), hi_xz[j]);
+            const float fz = floorf(zs / deltas[j]);
+            bin_z[e] = (int)fz;
+            res_z_norm[e] = (zs - (fz + 0.5f) * deltas[j]) / deltas[j];
+        }
+        const float ft = floorf(dshift / delta_theta);
+        bin_theta[i] = (int)ft;
+        res_theta_norm[i] = (dshift - (ft + 0.5f) * delta_theta) / half_delta_theta;
+        res_y[i] = dy;
+        for (int d = 0; d < 3; ++d) res_size_norm[i * 3 + d] = (bx[3 + d] - mean_sizes[i * 3 + d]) / mean_sizes[i * 3 + d];
+    }
+}

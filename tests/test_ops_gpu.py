@@ -973,6 +973,88 @@ def test_caller_side_ops_on_empty_and_ragged_shapes(hf, oracle_mod):
     assert y.shape == (1, 5) and torch.isfinite(y).all()
 
 
+# ------------------------------------------------------------------ glue either side of the ops
+@pytest.mark.parametrize("c", [1, 6, 32])
+def test_project_gather_against_oracle(hf, oracle_mod, c):
+    """fusion.project_gather (projection + int cast + gather_nd of image features, one kernel): pixels and gathered
+    rows bit-exact against the oracle, zeros outside the image, gradient = scatter-add onto the pixels"""
+    from heterofusionrcnn_amd.fusion import project_gather, rect_to_image
+    rng = np.random.default_rng(c)
+    b, p, h, w = 2, 5000, 37, 123
+    pts = np.stack([rng.uniform(-40, 40, (b, p)), rng.uniform(-3, 2, (b, p)), rng.uniform(0.5, 70, (b, p))], -1).astype(np.float32)
+    pts[0, :5, 2] = [-1.0, 0.0, 1e-30, np.inf, np.nan]          # behind the camera, zero / tiny / non-finite depth
+    calib = np.tile(np.array([[70.0, 0, 61.0, 4.0], [0, 70.0, 18.0, -0.2], [0, 0, 1, 0.003]], np.float32), (b, 1, 1))
+    calib[1, 0, 0] = 55.0
+    img = rng.standard_normal((b, h, w, c)).astype(np.float32)
+    im = dev(img).requires_grad_(True)
+    out, pix = project_gather(dev(pts), dev(calib), im, return_pixels=True)
+    o_out, o_pix = oracle_mod.project_gather(pts, calib, img)
+    assert np.array_equal(host(pix), o_pix) and np.array_equal(host(out), o_out)
+    inside = (o_pix[..., 0] >= 0) & (o_pix[..., 0] < w) & (o_pix[..., 1] >= 0) & (o_pix[..., 1] < h)
+    assert 0.2 < inside.mean() < 0.95 and not host(out)[~inside].any()
+    # the float pixels of the unfused form truncate to the same integers away from pixel edges
+    fp = host(rect_to_image(dev(pts), dev(calib)))
+    ok = inside & np.isfinite(fp).all(-1) & (np.abs(fp - np.round(fp)) > 1e-3).all(-1)
+    assert np.array_equal(np.trunc(fp[ok]).astype(np.int32), o_pix[ok])
+    go = rng.standard_normal((b, p, c)).astype(np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(host(im.grad), oracle_mod.project_gather_grad(img.shape, o_pix, go), rtol=0, atol=1e-4)
+    empty = project_gather(dev(np.zeros((2, 0, 3), np.float32)), dev(calib), dev(img))
+    assert empty.shape == (2, 0, c)
+    with pytest.raises(ValueError):
+        project_gather(dev(pts), dev(calib[:, :2]), dev(img))
+
+
+@pytest.mark.parametrize("rank,with_theta", [(3, False), (3, True), (2, True)])
+def test_bin_box_codec_against_oracle(hf, oracle_mod, rank, with_theta):
+    """box_codec.encode / decode (bin_based_box3d_encoder.py as one kernel each) against the oracle: bit-exact without
+    a reference heading (no trigonometry), 1e-5 with one (sin/cos differ by ulps between ocml and glibc); bins equal
+    away from bin edges; encode -> decode reproduces the boxes"""
+    from heterofusionrcnn_amd import box_codec
+    rng = np.random.default_rng(rank * 2 + with_theta)
+    ss, deltas, r, nbt, k = [3.0, 1.5], [0.5, 0.25], 0.25 * np.pi, 12, 2
+    dt = 2 * r / nbt
+    lead = (3, 700) if rank == 3 else (2100,)
+    rows = int(np.prod(lead))
+    ref = rng.uniform(-30, 30, lead + (3,)).astype(np.float32)
+    th = rng.uniform(-3, 3, lead).astype(np.float32) if with_theta else None
+    boxes = np.empty(lead + (7,), np.float32)
+    boxes[..., :3] = ref + rng.uniform(-1.0, 1.0, lead + (3,))
+    boxes[..., 3:6] = rng.uniform(0.5, 4.0, lead + (3,))
+    boxes[..., 6] = rng.uniform(-0.9 * r, 0.9 * r, lead) + (th if with_theta else 0)
+    mean = rng.uniform(1, 3, lead + (3,)).astype(np.float32)
+    got = box_codec.encode(dev(ref), dev(th) if with_theta else 0, dev(boxes), dev(mean), ss, deltas, r, dt, k)
+    want = oracle_mod.bin_box_encode(ref.reshape(rows, 3), th.reshape(rows) if with_theta else None, boxes.reshape(rows, 7),
+                                     mean.reshape(rows, 3), ss, deltas, r, dt, k, rcnn=rank == 2)
+    shapes = [lead + (k,)] * 4 + [lead, lead, lead, lead + (3,)]
+    for g, wv, shp in zip(got, want, shapes):
+        assert tuple(g.shape) == shp
+        g = host(g).reshape(wv.shape)
+        if not with_theta:
+            assert np.array_equal(g, wv)
+        elif g.dtype == np.int32:
+            assert (g != wv).mean() < 2e-3      # a residual within an ulp of a bin edge may fall either side
+        else:
+            close = np.isclose(g, wv, rtol=0, atol=2e-5)
+            assert close.mean() > 0.998         # the same rows: their residual jumps by one bin
+    if rank == 3:
+        rep = lambda t, tail=(): t.unsqueeze(len(lead)).expand(*lead, k, *tail).contiguous()
+        dec = box_codec.decode(dev(ref), dev(th) if with_theta else 0, got[0], got[1], got[2], got[3], rep(got[4]), rep(got[5]),
+                               rep(got[6]), rep(got[7], (3,)), rep(dev(mean), (3,)), ss, deltas, r, dt)
+        assert dec.shape == lead + (k, 7)
+        for j in range(k):
+            np.testing.assert_allclose(host(dec[..., j, :]), boxes, rtol=0, atol=3e-4)
+        o_dec = oracle_mod.bin_box_decode(ref.reshape(rows, 3), th.reshape(rows) if with_theta else None,
+                                          *[host(t).reshape(rows, k) for t in (got[0], got[1], got[2], got[3], rep(got[4]),
+                                                                               rep(got[5]), rep(got[6]))],
+                                          host(rep(got[7], (3,))).reshape(rows, k, 3), host(rep(dev(mean), (3,))).reshape(rows, k, 3),
+                                          ss, deltas, r, dt)
+        if with_theta:
+            np.testing.assert_allclose(host(dec).reshape(rows, k, 7), o_dec, rtol=0, atol=1e-5)
+        else:
+            assert np.array_equal(host(dec).reshape(rows, k, 7), o_dec)
+
+
 def test_mlp_entry_points_reject_bad_arguments(hf):
     """argument checks of the caller-side entry points: HF_EINVAL -> ValueError, never a launch"""
     import ctypes
