@@ -184,6 +184,22 @@ def per_op_table(hf, xyz):
     t["pc_crop_512roi_R512_C288_us"] = time_op(lambda: hf.pc_crop_and_sample(xyz, fts, inten, msk, boxes8, box_ind, 512),
                                                iters=10, warm=2)
     t["pc_crop_out_GBs"] = nroi * 512 * (3 + 288 + 1) * 4 / t["pc_crop_512roi_R512_C288_us"] / 1e3
+    # glue either side of the ops: the LiDAR -> image fusion gather, the bin-based box decode of the RPN head
+    from heterofusionrcnn_amd import box_codec
+    from heterofusionrcnn_amd.fusion import project_gather
+    calib = torch.tensor([[700.0, 0, 300.0, 20.0], [0, 700.0, 90.0, -0.1], [0, 0, 1, 0.003]], device="cuda").repeat(B, 1, 1)
+    cam = torch.stack([xyz[..., 0] * 0.25, xyz[..., 1] * 0.25, xyz[..., 2] + 2.0], dim=-1).contiguous()
+    img_fts = torch.randn(B, 180, 600, 64, device="cuda")
+    t["project_gather_c64_us"] = time_op(lambda: project_gather(cam, calib, img_fts))
+    t["project_gather_c64_GBs"] = B * N0 * (12 + 2 * 64 * 4) / t["project_gather_c64_us"] / 1e3
+    kcls = 3
+    dec_in = [torch.randint(0, 12, (B, N0, kcls), device="cuda", dtype=torch.int32), torch.rand(B, N0, kcls, device="cuda") - .5,
+              torch.randint(0, 12, (B, N0, kcls), device="cuda", dtype=torch.int32), torch.rand(B, N0, kcls, device="cuda") - .5,
+              torch.randint(0, 12, (B, N0, kcls), device="cuda", dtype=torch.int32), torch.rand(B, N0, kcls, device="cuda") - .5,
+              torch.randn(B, N0, kcls, device="cuda"), torch.randn(B, N0, kcls, 3, device="cuda") * .1,
+              torch.rand(B, N0, kcls, 3, device="cuda") + 1]
+    t["bin_box_decode_16384x3_us"] = time_op(lambda: box_codec.decode(xyz, 0, *dec_in, [3.0] * kcls, [0.5] * kcls,
+                                                                     0.25 * np.pi, 0.5 * np.pi / 12))
     # two-stage inference flow of BASELINE config 5 (RPN -> NMS -> crop -> RCNN -> NMS), random weights
     from heterofusionrcnn_amd.two_stage import TwoStageDetector
     torch.manual_seed(0)
