@@ -58,3 +58,12 @@ def project_gather(pts3d, calib, img_fts, return_pixels=False):
     img_fts = dev_tensor(img_fts, torch.float32, "img_fts")
     out, pix = _ProjectGather.apply(img_fts, pts3d, calib)
     return (out, pix) if return_pixels else out
+
+
+def fuse_point_image_features(pc_fts, proj_img_fts, method="concat", div=2.0):
+    """hf/core/models/rpn_model.py:537-548: "mean" = (pc + img) / div (equal widths), "concat" = [pc, img]"""
+    if method == "mean":
+        require(pc_fts.shape[-1] == proj_img_fts.shape[-1], "mean fusion needs equal feature widths")
+        return (pc_fts + proj_img_fts) / div
+    require(method == "concat", "Invalid fusion method %r" % (method,))
+    return torch.cat([pc_fts, proj_img_fts], dim=-1)

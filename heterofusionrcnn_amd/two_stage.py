@@ -3,6 +3,7 @@
 What is restated from the reference is the DATA FLOW between the ops, not its network bodies:
 
   RPN forward -> per-point scores + boxes            hf/core/models/rpn_model.py:585-642
+  (optional) LiDAR -> image fusion: project, gather  rpn_model.py:227-235, 537-548, 860 (fusion.project_gather)
   top-k pre_nms_size, oriented NMS, nms_size         rpn_model.py:645-687, model_util.py:101-142
   expand proposals by the pooling context            hf/core/models/rcnn_model.py:462-476
   box corners -> pc_crop_and_sample(resize)          rcnn_model.py:478-489
@@ -22,6 +23,7 @@ import torch.nn as nn
 from . import dp, modules
 from .bev_iou import oriented_nms_batched
 from .cropping import pc_crop_and_sample
+from .fusion import fuse_point_image_features, project_gather
 
 
 def canonical_transform(pts, boxes_3d):
@@ -62,24 +64,32 @@ class BoxHead(nn.Module):
 
 class TwoStageDetector(nn.Module):
     def __init__(self, pre_nms_size=9000, rpn_nms_thresh=0.8, rpn_nms_size=100, roi_crop_size=512, context=1.0,
-                 rcnn_nms_thresh=0.01, rcnn_nms_size=100, rpn_feat=128):
+                 rcnn_nms_thresh=0.01, rcnn_nms_size=100, rpn_feat=128, img_channels=0):
+        """img_channels > 0: the image branch's feature map (B,H,W,img_channels) and the P2 calibration are passed to
+        forward(); the features under the projected points are concatenated to the point features for the RPN head
+        and for the RCNN crop (the reference's "concat" fusion and its saved output_fts)."""
         super().__init__()
+        self.img_channels = img_channels
         self.pre_nms_size, self.rpn_nms_thresh, self.rpn_nms_size = pre_nms_size, rpn_nms_thresh, rpn_nms_size
         self.roi_crop_size, self.context = roi_crop_size, context
         self.rcnn_nms_thresh, self.rcnn_nms_size = rcnn_nms_thresh, rcnn_nms_size
         self.rpn = modules.PointnetSAFPStack(in_channel=1)
         assert self.rpn.out_channel == rpn_feat
-        self.rpn_head = BoxHead(rpn_feat)
-        cin = rpn_feat + 1 + 1  # cropped features + intensity + foreground mask (rcnn_model.py:178-182, 505-520)
+        self.rpn_head = BoxHead(rpn_feat + img_channels)
+        # cropped features (point + image) + intensity + foreground mask (rcnn_model.py:178-182, 505-520)
+        cin = rpn_feat + img_channels + 1 + 1
         self.rcnn_sa1 = modules.PointnetSAModule(128, 0.4, 16, cin, [128, 128])
         self.rcnn_sa2 = modules.PointnetSAModule(32, 0.8, 16, 128, [128, 256])
         self.rcnn_sa3 = modules.PointnetSAModule(None, None, None, 256, [256, 512], group_all=True)
         self.rcnn_head = BoxHead(512)
 
     @torch.no_grad()
-    def rpn_stage(self, xyz, intensity, geometry=None):
+    def rpn_stage(self, xyz, intensity, geometry=None, img_fts=None, calib=None):
         """geometry: self.rpn.geometry(xyz) computed ahead (pipeline.GeometryPrefetcher), or None to do it inline"""
         feats = self.rpn(xyz, intensity, geometry=geometry)                # (B,N,C)
+        if self.img_channels:
+            assert img_fts is not None and calib is not None and img_fts.shape[-1] == self.img_channels
+            feats = fuse_point_image_features(feats, project_gather(xyz, calib, img_fts), "concat")
         scores, boxes = self.rpn_head(feats, xyz)                          # (B,N), (B,N,7)
         k = min(self.pre_nms_size, xyz.shape[1])
         top_s, top_i = torch.topk(scores, k, dim=1)                        # rpn_model.py:647-655, sorted descending
@@ -122,8 +132,8 @@ class TwoStageDetector(nn.Module):
         return detections
 
     @torch.no_grad()
-    def forward(self, xyz, intensity, geometry=None):
-        feats, proposals, _, point_scores = self.rpn_stage(xyz, intensity, geometry)
+    def forward(self, xyz, intensity, geometry=None, img_fts=None, calib=None):
+        feats, proposals, _, point_scores = self.rpn_stage(xyz, intensity, geometry, img_fts, calib)
         return self.rcnn_stage(xyz, feats, intensity, point_scores, proposals)
 
 

@@ -1086,6 +1086,33 @@ def test_mlp_entry_points_reject_bad_arguments(hf):
     assert L.hf_linear_wgrad_workspace(0, 4, 4) == 0
 
 
+def test_two_stage_with_image_fusion_branch(hf):
+    """the optional image branch: features under the projected points are concatenated to the point features for the
+    RPN head and for the RCNN crop; points that project outside the image contribute zeros"""
+    from heterofusionrcnn_amd.fusion import fuse_point_image_features, project_gather
+    from heterofusionrcnn_amd.two_stage import TwoStageDetector
+    torch.manual_seed(5)
+    rng = np.random.default_rng(5)
+    det = TwoStageDetector(pre_nms_size=1024, rpn_nms_size=16, roi_crop_size=64, img_channels=8).cuda().eval()
+    xyz = dev(kitti_uniform(rng, 2, 16384))
+    inten = dev(rng.uniform(-.5, .5, (2, 16384, 1)).astype(np.float32))
+    img = dev(rng.standard_normal((2, 48, 160, 8)).astype(np.float32))
+    calib = dev(np.tile(np.array([[90.0, 0, 80, 5], [0, 90.0, 24, 0], [0, 0, 1, 0.003]], np.float32), (2, 1, 1)))
+    feats, proposals, _, scores = det.rpn_stage(xyz, inten, None, img, calib)
+    assert feats.shape == (2, 16384, 128 + 8) and proposals.shape == (2, 16, 7)
+    proj, pix = project_gather(xyz, calib, img, return_pixels=True)
+    assert torch.equal(feats[..., 128:], proj)
+    outside = (pix[..., 0] < 0) | (pix[..., 0] >= 160) | (pix[..., 1] < 0) | (pix[..., 1] >= 48)
+    assert outside.any() and not feats[..., 128:][outside].any()
+    dets = det(xyz, inten, img_fts=img, calib=calib)
+    assert len(dets) == 2 and all(d["boxes"].shape[1] == 7 for d in dets)
+    a, b = torch.randn(3, 5, 4, device="cuda"), torch.randn(3, 5, 4, device="cuda")
+    assert torch.equal(fuse_point_image_features(a, b, "mean"), (a + b) / 2.0)
+    assert fuse_point_image_features(a, b, "concat").shape == (3, 5, 8)
+    with pytest.raises(ValueError):
+        fuse_point_image_features(a, b, "max")
+
+
 def test_batched_nms_equals_per_frame(hf, oracle_mod):
     rng = np.random.default_rng(8)
     frames = np.stack([_clustered(rng, 30, 10) for _ in range(3)])
