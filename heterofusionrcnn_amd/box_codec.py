@@ -39,13 +39,13 @@ def decode(ref_pts, ref_theta, bin_x, res_x_norm, bin_z, res_z_norm, bin_theta, 
     ss, deltas = _f32(dev, Ss), _f32(dev, DELTAs)
     require(ss.numel() == k and deltas.numel() == k, "Ss / DELTAs must have one entry per class")
     boxes = torch.empty(lead + (k, 7), dtype=torch.float32, device=dev)
-    check(_lib.lib().hf_bin_box_decode(rows, k, ptr(f(ref_pts, "ref_pts")), ptr(_theta(ref_theta, rows, dev)),
-                                       ptr(i(bin_x, "bin_x")), ptr(f(res_x_norm, "res_x_norm")), ptr(i(bin_z, "bin_z")),
-                                       ptr(f(res_z_norm, "res_z_norm")), ptr(i(bin_theta, "bin_theta")),
-                                       ptr(f(res_theta_norm, "res_theta_norm")), ptr(f(res_y, "res_y")),
-                                       ptr(f(res_size_norm, "res_size_norm")), ptr(f(mean_sizes, "mean_sizes")), ptr(ss),
-                                       ptr(deltas), float(np.float32(R)), float(np.float32(DELTA_THETA)), ptr(boxes),
-                                       stream_ptr()), "bin_box_decode")
+    # converted / reshaped operands are held in `args` until the launch is enqueued (a temporary freed earlier could be
+    # handed out again by the caching allocator and overwritten by the next conversion)
+    args = [f(ref_pts, "ref_pts"), _theta(ref_theta, rows, dev), i(bin_x, "bin_x"), f(res_x_norm, "res_x_norm"),
+            i(bin_z, "bin_z"), f(res_z_norm, "res_z_norm"), i(bin_theta, "bin_theta"), f(res_theta_norm, "res_theta_norm"),
+            f(res_y, "res_y"), f(res_size_norm, "res_size_norm"), f(mean_sizes, "mean_sizes"), ss, deltas]
+    check(_lib.lib().hf_bin_box_decode(rows, k, *[ptr(a) for a in args], float(np.float32(R)),
+                                       float(np.float32(DELTA_THETA)), ptr(boxes), stream_ptr()), "bin_box_decode")
     return boxes
 
 
@@ -64,11 +64,45 @@ def encode(ref_pts, ref_theta, boxes_3d, mean_sizes, Ss, DELTAs, R, DELTA_THETA,
     e = lambda shape, dt: torch.empty(lead + shape, dtype=dt, device=dev)
     bin_x, res_x, bin_z, res_z = e((k,), torch.int32), e((k,), torch.float32), e((k,), torch.int32), e((k,), torch.float32)
     bin_t, res_t, res_y, res_s = e((), torch.int32), e((), torch.float32), e((), torch.float32), e((3,), torch.float32)
-    check(_lib.lib().hf_bin_box_encode(rows, k, 1 if ref_pts.dim() == 2 else 0, ptr(f(ref_pts, "ref_pts")),
-                                       ptr(_theta(ref_theta, rows, dev)), ptr(f(boxes_3d, "boxes_3d")),
-                                       ptr(f(mean_sizes, "mean_sizes")), ptr(ss), ptr(deltas), ptr(hi_xz),
+    args = [f(ref_pts, "ref_pts"), _theta(ref_theta, rows, dev), f(boxes_3d, "boxes_3d"), f(mean_sizes, "mean_sizes"), ss,
+            deltas, hi_xz]  # held until the launch is enqueued, see decode()
+    check(_lib.lib().hf_bin_box_encode(rows, k, 1 if ref_pts.dim() == 2 else 0, *[ptr(a) for a in args],
                                        float(np.float32(R)), float(np.float32(2.0 * float(R) - 1e-3)),
                                        float(np.float32(DELTA_THETA)), float(np.float32(0.5 * float(DELTA_THETA))),
                                        ptr(bin_x), ptr(res_x), ptr(bin_z), ptr(res_z), ptr(bin_t), ptr(res_t), ptr(res_y),
                                        ptr(res_s), stream_ptr()), "bin_box_encode")
     return bin_x, res_x, bin_z, res_z, bin_t, res_t, res_y, res_s
+
+
+def decode_head(head, ref_pts, ref_theta, mean_sizes_k, num_bin_x, num_bin_z, num_bin_theta, Ss, DELTAs, R, DELTA_THETA,
+                cls=None):
+    """The decoding block of the RPN / RCNN heads as one kernel (rpn_model.py:593-642): head (..., K*D) or (..., K, D)
+    with D = 2*num_bin_x + 2*num_bin_z + 2*num_bin_theta + 4 -> boxes (..., K, 7), or (..., 7) when `cls` (...) picks
+    each row's class.  mean_sizes_k (K, 3) are the per-class mean sizes (`cluster_sizes`)."""
+    require(ref_pts.dim() in (2, 3) and ref_pts.shape[-1] == 3, "decode_head expects (B,p,3) or (N,3) ref_pts")
+    lead = tuple(ref_pts.shape[:-1])
+    rows = int(np.prod(lead)) if lead else 0
+    dev = ref_pts.device
+    ms = torch.as_tensor(np.asarray(mean_sizes_k, dtype=np.float32), device=dev) if not isinstance(mean_sizes_k, torch.Tensor) \
+        else dev_tensor(mean_sizes_k.detach(), torch.float32, "mean_sizes_k")
+    require(ms.dim() == 2 and ms.shape[1] == 3, "mean_sizes_k must be (K, 3)")
+    k = ms.shape[0]
+    d = 2 * num_bin_x + 2 * num_bin_z + 2 * num_bin_theta + 4
+    require(head.numel() == rows * k * d, "head must hold K * (2*nbx + 2*nbz + 2*nbt + 4) values per reference point")
+    head = dev_tensor(head.detach().reshape(rows, k * d), torch.float32, "head")
+    ss, deltas = _f32(dev, Ss), _f32(dev, DELTAs)
+    require(ss.numel() == k and deltas.numel() == k, "Ss / DELTAs must have one entry per class")
+    c = None
+    if cls is not None:
+        c = dev_tensor(cls.detach().reshape(rows).to(torch.int32), torch.int32, "cls")
+        boxes = torch.zeros(lead + (7,), dtype=torch.float32, device=dev)
+    else:
+        boxes = torch.empty(lead + (k, 7), dtype=torch.float32, device=dev)
+    ref = dev_tensor(ref_pts.detach().reshape(rows, 3), torch.float32, "ref_pts")
+    theta = _theta(ref_theta, rows, dev)
+    ms = ms.contiguous()  # every operand has a name here: nothing is freed before the launch is enqueued
+    check(_lib.lib().hf_bin_head_decode(rows, k, num_bin_x, num_bin_z, num_bin_theta, ptr(head), ptr(ref), ptr(theta),
+                                        ptr(ms), ptr(ss), ptr(deltas), float(np.float32(R)),
+                                        float(np.float32(DELTA_THETA)), ptr(c), ptr(boxes), stream_ptr()),
+          "bin_head_decode")
+    return boxes

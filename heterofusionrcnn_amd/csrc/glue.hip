@@ -103,6 +103,52 @@ __global__ void bin_box_decode_kernel(long long rows, int k, const float *__rest
     }
 }
 
+// The decoding block of the RPN / RCNN heads in one pass: slice the head vector (rpn_model.py:870-935), arg-max each
+// logit slice (first maximum, as tf.argmax), pick the residual of the winning bin (:248-290), decode (tf_decode) with the
+// per-class mean size, optionally keep only the row's predicted class (:237-246).  One thread per (row, class).
+__global__ void bin_head_decode_kernel(long long rows, int k, int nbx, int nbz, int nbt, const float *__restrict__ head,
+                                       const float *__restrict__ ref_pts, const float *__restrict__ ref_theta,
+                                       const float *__restrict__ mean_sizes_k, const float *__restrict__ ss,
+                                       const float *__restrict__ deltas, float r, float delta_theta,
+                                       const int *__restrict__ cls, float *__restrict__ boxes)
+{
+    const int d = 2 * nbx + 2 * nbz + 2 * nbt + 4;
+    const long long total = rows * k;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long i = e / k;
+        const int j = static_cast<int>(e - i * k);
+        if (cls && cls[i] != j) continue;
+        const float *v = head + e * d;
+        int bx = 0, bz = 0, bt = 0;
+        float best = v[0];
+        for (int q = 1; q < nbx; ++q) { const float x = v[q]; if (x > best) { best = x; bx = q; } }
+        const float *vz = v + 2 * nbx;
+        best = vz[0];
+        for (int q = 1; q < nbz; ++q) { const float x = vz[q]; if (x > best) { best = x; bz = q; } }
+        const float *vt = v + 2 * nbx + 2 * nbz;
+        best = vt[0];
+        for (int q = 1; q < nbt; ++q) { const float x = vt[q]; if (x > best) { best = x; bt = q; } }
+        const float rx = v[nbx + bx], rz = vz[nbz + bz], rt = vt[nbt + bt];
+        const float *tail = v + 2 * nbx + 2 * nbz + 2 * nbt;
+        const float th0 = ref_theta ? ref_theta[i] : 0.0f;
+        float dx = (static_cast<float>(bx) + 0.5f) * deltas[j] - ss[j] + rx * deltas[j];
+        float dz = (static_cast<float>(bz) + 0.5f) * deltas[j] - ss[j] + rz * deltas[j];
+        if (ref_theta) {
+            const float sn = sinf(th0), cs = cosf(th0);
+            const float ax = cs * dx + sn * dz, az = -sn * dx + cs * dz;
+            dx = ax; dz = az;
+        }
+        float *o = cls ? boxes + i * 7 : boxes + e * 7;
+        o[0] = dx + ref_pts[i * 3 + 0];
+        o[1] = tail[0] + ref_pts[i * 3 + 1];
+        o[2] = dz + ref_pts[i * 3 + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[3 + c] = mean_sizes_k[j * 3 + c] + tail[1 + c] * mean_sizes_k[j * 3 + c];
+        o[6] = th0 + (static_cast<float>(bt) + 0.5f) * delta_theta - r + rt * 0.5f * delta_theta;
+    }
+}
+
 __device__ __forceinline__ float floormodf(float x, float y)
 {
     float r = fmodf(x, y);
@@ -245,5 +291,17 @@ HF_API int hf_bin_box_encode(long long rows, int k, int rcnn, const float *ref_p
                        ref_pts, ref_theta, boxes, mean_sizes, ss, deltas, hi_xz, r, hi_theta, delta_theta,
                        half_delta_theta, bin_x, res_x_norm, bin_z, res_z_norm, bin_theta, res_theta_norm, res_y,
                        res_size_norm);
+    return launch_status();
+}
+
+HF_API int hf_bin_head_decode(long long rows, int k, int nbx, int nbz, int nbt, const float *head, const float *ref_pts,
+                              const float *ref_theta, const float *mean_sizes_k, const float *ss, const float *deltas,
+                              float r, float delta_theta, const int *cls, float *boxes, hf_stream_t stream)
+{
+    if (rows < 0 || k <= 0 || nbx <= 0 || nbz <= 0 || nbt <= 0) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    if (!head || !ref_pts || !mean_sizes_k || !ss || !deltas || !boxes) return HF_EINVAL;
+    hipLaunchKernelGGL(bin_head_decode_kernel, dim3(glue_grid(rows * k, 256)), dim3(256), 0, as_stream(stream), rows, k, nbx,
+                       nbz, nbt, head, ref_pts, ref_theta, mean_sizes_k, ss, deltas, r, delta_theta, cls, boxes);
     return launch_status();
 }

@@ -20,7 +20,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import dp, modules
+from . import box_codec, dp, modules
 from .bev_iou import oriented_nms_batched
 from .cropping import pc_crop_and_sample
 from .fusion import fuse_point_image_features, project_gather
@@ -45,21 +45,26 @@ def expand_proposals(proposals, context):
 
 
 class BoxHead(nn.Module):
-    """per-point / per-RoI score and a box decoded around an anchor position (stand-in for the bin-based heads)"""
+    """Per-point / per-RoI score and a bin-based box around a reference position: the output layout and the decoding
+    of the reference's heads (rpn_model.py:570-642; rcnn_model.py decodes the same way around the proposal, with its
+    heading as ref_theta), one class.  The fc stack in front of it is a single Linear here (random weights)."""
 
-    def __init__(self, cin, mean_size=(3.9, 1.6, 1.5)):
+    def __init__(self, cin, mean_size=(3.9, 1.6, 1.5), search_range=3.0, bin_len=0.5, theta_range=0.25, theta_bins=12):
         super().__init__()
+        self.nb_xz = int(2 * search_range / bin_len)           # NUM_BIN_X = NUM_BIN_Z (rpn_model.py:115-116)
+        self.nb_theta = theta_bins
+        self.ss, self.deltas = [search_range], [bin_len]
+        self.r = theta_range * math.pi                          # rpn_model.py:118-119
+        self.delta_theta = 2 * self.r / theta_bins
         self.cls = nn.Linear(cin, 1)
-        self.reg = nn.Linear(cin, 7)
-        self.register_buffer("mean_size", torch.tensor(mean_size))
+        self.reg = nn.Linear(cin, 4 * self.nb_xz + 2 * self.nb_theta + 4)
+        self.register_buffer("mean_size", torch.tensor([list(mean_size)]))
 
-    def forward(self, feats, anchors_xyz):
+    def forward(self, feats, ref_xyz, ref_theta=0):
         score = torch.sigmoid(self.cls(feats)).squeeze(-1)
-        r = self.reg(feats)
-        centre = anchors_xyz + torch.tanh(r[..., 0:3]) * 1.5
-        size = self.mean_size * torch.exp(torch.clamp(r[..., 3:6], -0.5, 0.5))
-        ry = math.pi * torch.tanh(r[..., 6:7])
-        return score, torch.cat([centre, size, ry], dim=-1)
+        boxes = box_codec.decode_head(self.reg(feats), ref_xyz, ref_theta, self.mean_size, self.nb_xz, self.nb_xz,
+                                      self.nb_theta, self.ss, self.deltas, self.r, self.delta_theta)
+        return score, boxes.squeeze(-2)
 
 
 class TwoStageDetector(nn.Module):
@@ -115,7 +120,7 @@ class TwoStageDetector(nn.Module):
         x1, f1, _ = self.rcnn_sa1(pts_ct, pts_in)
         x2, f2, _ = self.rcnn_sa2(x1, f1)
         _, f3, _ = self.rcnn_sa3(x2, f2)
-        score, refined = self.rcnn_head(f3.squeeze(1), flat[:, 0:3])
+        score, refined = self.rcnn_head(f3.squeeze(1), flat[:, 0:3].contiguous(), flat[:, 6].contiguous())
         score = score * non_empty.float()                                   # empty RoIs carry no evidence
         # model_util.py:101-142 / rcnn_model.py:731-778 for all frames at once: sort by score, ONE batched oriented
         # NMS, drop the keep[0] padding (= keep the first `num` entries), one host read of the counts

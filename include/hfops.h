@@ -319,6 +319,15 @@ int hf_bin_box_encode(long long rows, int k, int rcnn, const float *ref_pts, con
                       float *res_z_norm, int *bin_theta, float *res_theta_norm, float *res_y, float *res_size_norm,
                       hf_stream_t stream);
 
+/* The decoding block of the RPN / RCNN heads in one pass (hf/core/models/rpn_model.py:870-935 parse, :593-605 argmax,
+ * :248-290 residual gather, :609-639 mean sizes + tf_decode, :237-246 class gather).  head (rows, k, d) with
+ * d = 2*nbx + 2*nbz + 2*nbt + 4 laid out [bin_x logits | res_x_norms | bin_z logits | res_z_norms | bin_theta logits |
+ * res_theta_norms | res_y | res_size_norm(3)]; mean_sizes_k (k, 3).  cls == NULL: boxes (rows, k, 7); cls (rows,) int32:
+ * boxes (rows, 7), the decoded box of each row's class (rows whose cls is outside [0, k) are left untouched). */
+int hf_bin_head_decode(long long rows, int k, int nbx, int nbz, int nbt, const float *head, const float *ref_pts,
+                       const float *ref_theta, const float *mean_sizes_k, const float *ss, const float *deltas, float r,
+                       float delta_theta, const int *cls, float *boxes, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

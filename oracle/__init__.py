@@ -370,3 +370,17 @@ def bin_box_encode(ref_pts, ref_theta, boxes, mean_sizes, ss, deltas, r, delta_t
                              ctypes.c_float(np.float32(delta_theta)), ctypes.c_float(np.float32(0.5 * float(delta_theta))),
                              *[_p(o) for o in outs])
     return tuple(outs)
+
+
+def bin_head_decode(head, ref_pts, ref_theta, mean_sizes_k, nbx, nbz, nbt, ss, deltas, r, delta_theta, cls=None):
+    """head (rows, k, d); -> boxes (rows, k, 7) or (rows, 7) with cls"""
+    rows, k, _ = head.shape
+    boxes = np.zeros((rows, 7), np.float32) if cls is not None else np.empty((rows, k, 7), np.float32)
+    th = _f(ref_theta) if ref_theta is not None else None
+    c = _i(cls) if cls is not None else None
+    lib().hfo_bin_head_decode(ctypes.c_longlong(rows), k, nbx, nbz, nbt, _p(_f(head)), _p(_f(ref_pts)),
+                              _p(th) if th is not None else None, _p(_f(mean_sizes_k)),
+                              _p(_f(np.asarray(ss, np.float64).astype(np.float32))),
+                              _p(_f(np.asarray(deltas, np.float64).astype(np.float32))), ctypes.c_float(np.float32(r)),
+                              ctypes.c_float(np.float32(delta_theta)), _p(c) if c is not None else None, _p(boxes))
+    return boxes

@@ -757,3 +757,45 @@ HFO_API void hfo_bin_box_encode(long long rows, int k, int rcnn, const float *re
         for (int d = 0; d < 3; ++d) res_size_norm[i * 3 + d] = (bx[3 + d] - mean_sizes[i * 3 + d]) / mean_sizes[i * 3 + d];
     }
 }
+
+/* hfo_bin_head_decode -- the decoding block of the RPN / RCNN heads as one function: _parse_rpn_output
+ * (hf/core/models/rpn_model.py:870-935: slices [bin_x logits | res_x_norms | bin_z logits | res_z_norms | bin_theta logits |
+ * res_theta_norms | res_y | res_size_norm(3)] of each (row, class) vector of length d = 2*nbx + 2*nbz + 2*nbt + 4),
+ * tf.argmax over each logit slice (first maximum), _gather_residuals (:248-290), per-class mean sizes tiled over the
+ * rows (:609-621), tf_decode (:623-639) and, with cls != NULL, _gather_cls_proposals (:237-246, 640-642): row i keeps
+ * only class cls[i] -> boxes (rows, 7); otherwise boxes (rows, k, 7). */
+HFO_API void hfo_bin_head_decode(long long rows, int k, int nbx, int nbz, int nbt, const float *head,
+                                 const float *ref_pts, const float *ref_theta, const float *mean_sizes_k,
+                                 const float *ss, const float *deltas, float r, float delta_theta, const int *cls,
+                                 float *boxes)
+{
+    const int d = 2 * nbx + 2 * nbz + 2 * nbt + 4;
+    for (long long i = 0; i < rows; ++i) {
+        const float th0 = ref_theta ? ref_theta[i] : 0.0f;
+        const float sn = ref_theta ? sinf(th0) : 0.0f, cs = ref_theta ? cosf(th0) : 1.0f;
+        for (int j = 0; j < k; ++j) {
+            if (cls && cls[i] != j) continue;
+            const float *v = head + ((size_t)i * k + j) * d;
+            int bx = 0, bz = 0, bt = 0;
+            for (int q = 1; q < nbx; ++q) if (v[q] > v[bx]) bx = q;
+            const float *vz = v + 2 * nbx;
+            for (int q = 1; q < nbz; ++q) if (vz[q] > vz[bz]) bz = q;
+            const float *vt = v + 2 * nbx + 2 * nbz;
+            for (int q = 1; q < nbt; ++q) if (vt[q] > vt[bt]) bt = q;
+            const float rx = v[nbx + bx], rz = vz[nbz + bz], rt = vt[nbt + bt];
+            const float *tail = v + 2 * nbx + 2 * nbz + 2 * nbt;
+            float dx = ((float)bx + 0.5f) * deltas[j] - ss[j] + rx * deltas[j];
+            float dz = ((float)bz + 0.5f) * deltas[j] - ss[j] + rz * deltas[j];
+            if (ref_theta) {
+                const float ax = cs * dx + sn * dz, az = -sn * dx + cs * dz;
+                dx = ax; dz = az;
+            }
+            float *o = cls ? boxes + (size_t)i * 7 : boxes + ((size_t)i * k + j) * 7;
+            o[0] = dx + ref_pts[i * 3 + 0];
+            o[1] = tail[0] + ref_pts[i * 3 + 1];
+            o[2] = dz + ref_pts[i * 3 + 2];
+            for (int c = 0; c < 3; ++c) o[3 + c] = mean_sizes_k[j * 3 + c] + tail[1 + c] * mean_sizes_k[j * 3 + c];
+            o[6] = th0 + ((float)bt + 0.5f) * delta_theta - r + rt * 0.5f * delta_theta;
+        }
+    }
+}

@@ -93,3 +93,32 @@ def test_bin_codec_rcnn_orientation_folding():
     shift = bt * dt + dt / 2 + rt * dt / 2            # decoded dtheta_shift
     folded = np.array([0.1, 0.1, -0.2, 0.3])          # heading differences after folding
     np.testing.assert_allclose(shift, np.clip(folded + 0.5 * np.pi - Rr, 1e-3, 2 * Rr - 1e-3), atol=2e-4)
+
+
+def test_bin_head_decode_is_parse_argmax_gather_decode():
+    """the fused head decoding equals the reference's op-by-op route: slice, argmax (first maximum), take the winning
+    bin's residual, tile the class mean sizes, tf_decode, pick the row's class"""
+    rng = np.random.default_rng(9)
+    rows, k, nbx, nbz, nbt = 400, 2, 12, 12, 9
+    d = 2 * nbx + 2 * nbz + 2 * nbt + 4
+    head = rng.standard_normal((rows, k, d)).astype(np.float32)
+    head[:50, :, 3] = head[:50, :, 7] = 9.0          # tied maxima: the first one wins
+    ref = rng.uniform(-30, 30, (rows, 3)).astype(np.float32)
+    th = rng.uniform(-3, 3, rows).astype(np.float32)
+    ms = np.array([[3.9, 1.6, 1.5], [0.8, 0.6, 1.7]], np.float32)
+    dt = 2 * R / nbt
+    parts = np.split(head, np.cumsum([nbx, nbx, nbz, nbz, nbt, nbt, 1]), axis=-1)
+    bx, bz, bt = parts[0].argmax(-1), parts[2].argmax(-1), parts[4].argmax(-1)
+    assert (bx[:50] == 3).all()
+    take = lambda a, i: np.take_along_axis(a, i[..., None], -1)[..., 0]
+    want = oracle.bin_box_decode(ref, th, bx, take(parts[1], bx), bz, take(parts[3], bz), bt, take(parts[5], bt),
+                                 parts[6][..., 0], parts[7], np.broadcast_to(ms, (rows, k, 3)), SS, DELTAS, R, dt)
+    got = oracle.bin_head_decode(head, ref, th, ms, nbx, nbz, nbt, SS, DELTAS, R, dt)
+    assert np.array_equal(got, want)
+    cls = rng.integers(0, k, rows).astype(np.int32)
+    one = oracle.bin_head_decode(head, ref, th, ms, nbx, nbz, nbt, SS, DELTAS, R, dt, cls=cls)
+    assert np.array_equal(one, want[np.arange(rows), cls])
+    assert np.array_equal(oracle.bin_head_decode(head, ref, None, ms, nbx, nbz, nbt, SS, DELTAS, R, dt),
+                          oracle.bin_box_decode(ref, None, bx, take(parts[1], bx), bz, take(parts[3], bz), bt,
+                                                take(parts[5], bt), parts[6][..., 0], parts[7],
+                                                np.broadcast_to(ms, (rows, k, 3)), SS, DELTAS, R, dt))

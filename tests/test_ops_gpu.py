@@ -1055,6 +1055,44 @@ def test_bin_box_codec_against_oracle(hf, oracle_mod, rank, with_theta):
             assert np.array_equal(host(dec).reshape(rows, k, 7), o_dec)
 
 
+@pytest.mark.parametrize("with_theta,with_cls", [(False, False), (True, False), (False, True), (True, True)])
+def test_bin_head_decode_against_oracle(hf, oracle_mod, with_theta, with_cls):
+    """box_codec.decode_head (slice + argmax + residual gather + decode + class gather, one kernel) against the oracle:
+    bit-exact without a reference heading, 1e-5 with one; equal to the op-by-op torch route"""
+    from heterofusionrcnn_amd import box_codec
+    rng = np.random.default_rng(11 + 2 * with_theta + with_cls)
+    b, p, k, nbx, nbz, nbt = 2, 3000, 3, 12, 12, 12
+    ss, deltas, r = [3.0, 1.5, 1.5], [0.5, 0.25, 0.25], 0.25 * np.pi
+    dt = 2 * r / nbt
+    d = 2 * nbx + 2 * nbz + 2 * nbt + 4
+    head = rng.standard_normal((b, p, k * d)).astype(np.float32)
+    head.reshape(b, p, k, d)[0, :40, :, 2] = head.reshape(b, p, k, d)[0, :40, :, 9] = 7.5     # ties
+    ref = rng.uniform(-30, 30, (b, p, 3)).astype(np.float32)
+    th = rng.uniform(-3, 3, (b, p)).astype(np.float32) if with_theta else None
+    ms = np.array([[3.9, 1.6, 1.5], [0.8, 0.6, 1.7], [1.8, 0.6, 1.7]], np.float32)
+    cls = rng.integers(0, k, (b, p)).astype(np.int32) if with_cls else None
+    got = box_codec.decode_head(dev(head), dev(ref), dev(th) if with_theta else 0, ms, nbx, nbz, nbt, ss, deltas, r, dt,
+                                cls=dev(cls) if with_cls else None)
+    want = oracle_mod.bin_head_decode(head.reshape(b * p, k, d), ref.reshape(-1, 3), th.reshape(-1) if with_theta else None,
+                                      ms, nbx, nbz, nbt, ss, deltas, r, dt, cls=cls.reshape(-1) if with_cls else None)
+    assert tuple(got.shape) == ((b, p, 7) if with_cls else (b, p, k, 7))
+    if with_theta:
+        np.testing.assert_allclose(host(got).reshape(want.shape), want, rtol=0, atol=1e-5)
+    else:
+        assert np.array_equal(host(got).reshape(want.shape), want)
+    # the op-by-op route on the device
+    hv = dev(head).view(b, p, k, d)
+    sl = torch.split(hv, [nbx, nbx, nbz, nbz, nbt, nbt, 1, 3], dim=-1)
+    bx, bz, bt = sl[0].argmax(-1), sl[2].argmax(-1), sl[4].argmax(-1)
+    take = lambda a, i: torch.gather(a, -1, i.unsqueeze(-1)).squeeze(-1)
+    route = box_codec.decode(dev(ref), dev(th) if with_theta else 0, bx, take(sl[1], bx), bz, take(sl[3], bz), bt,
+                             take(sl[5], bt), sl[6].squeeze(-1), sl[7].contiguous(),
+                             dev(ms).expand(b, p, k, 3).contiguous(), ss, deltas, r, dt)
+    if with_cls:
+        route = torch.gather(route, 2, dev(cls).long().view(b, p, 1, 1).expand(b, p, 1, 7)).squeeze(2)
+    assert torch.equal(got, route)
+
+
 def test_mlp_entry_points_reject_bad_arguments(hf):
     """argument checks of the caller-side entry points: HF_EINVAL -> ValueError, never a launch"""
     import ctypes
