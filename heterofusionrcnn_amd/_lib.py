@@ -47,8 +47,8 @@ _SIGNATURES = {
     "hf_bn_relu_fwd_train": [ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_bn_relu_fwd_eval": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "hf_bn_relu_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "hf_group_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "hf_group_concat_grad": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "hf_group_concat": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "hf_group_concat_grad": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_three_interpolate_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_three_interpolate_concat_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_bn_stats": [ctypes.c_longlong, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp],

@@ -580,13 +580,15 @@ __global__ void group_point_grad_kernel(int n, int c, long long rows_per_batch, 
 // ------------------------------------------------------------------------------------------
 // group_concat: the concat of sample_and_group (pointnet_util.py:58-60) written directly,
 //   out[b,j,k,:] = [ grouped_xyz[b,j,k,0:3], points[b, idx[b,j,k], 0:c], 0 ... ]   (row width `width` >= 3 + c)
+// or, xyz_last (the multi-scale module's order, pointnet_util.py:264): [ points[...], grouped_xyz[...], 0 ... ]
 // instead of group_point into a temporary followed by a concat that reads and writes everything again.  The zero
 // columns pad rows to a multiple of 4 floats so that the GEMM that consumes them can use 16-byte accesses
 // (3 + C is never a multiple of 4 for the usual C = 64, 128).  One float4 of output per lane.
 // ------------------------------------------------------------------------------------------
-__global__ void group_concat_kernel(int n, int c, int w4, long long rows_per_batch, long long nrows,
-                                    const float *__restrict__ gxyz, const float *__restrict__ points,
-                                    const int *__restrict__ idx, float *__restrict__ out)
+__global__ void group_concat_kernel(int n, int c, int w4, int xyz_col, int feat_col, long long rows_per_batch,
+                                    long long nrows, const float *__restrict__ gxyz,
+                                    const float *__restrict__ points, const int *__restrict__ idx,
+                                    float *__restrict__ out)
 {
     const long long total = nrows * w4;
     for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
@@ -594,20 +596,21 @@ __global__ void group_concat_kernel(int n, int c, int w4, long long rows_per_bat
         const long long row = e / w4;
         const int q = static_cast<int>(e - row * w4);
         const long long bb = row / rows_per_batch;
-        const float *src = points + (bb * n + idx[row]) * c - 3;  // column j of the output row is src[j] for 3 <= j < 3 + c
+        const float *src = points + (bb * n + idx[row]) * c;
         const float *g = gxyz + row * 3;
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = q * 4 + i;
-            v[i] = j < 3 ? g[j] : (j < 3 + c ? src[j] : 0.0f);
+            const int jf = j - feat_col, jx = j - xyz_col;
+            v[i] = (jf >= 0 && jf < c) ? src[jf] : ((jx >= 0 && jx < 3) ? g[jx] : 0.0f);
         }
         *reinterpret_cast<float4 *>(out + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
 // gradient w.r.t. points: the feature columns 3..3+c of every row scattered back (target zeroed by the caller)
-__global__ void group_concat_grad_kernel(int n, int c, int width, long long rows_per_batch, long long nrows,
+__global__ void group_concat_grad_kernel(int n, int c, int width, int feat_col, long long rows_per_batch, long long nrows,
                                          const float *__restrict__ grad_out, const int *__restrict__ idx,
                                          float *__restrict__ grad_points)
 {
@@ -617,7 +620,7 @@ __global__ void group_concat_grad_kernel(int n, int c, int width, long long rows
         const long long row = e / c;
         const int l = static_cast<int>(e - row * c);
         const long long bb = row / rows_per_batch;
-        atomicAdd(grad_points + (bb * n + idx[row]) * c + l, grad_out[row * width + 3 + l]);
+        atomicAdd(grad_points + (bb * n + idx[row]) * c + l, grad_out[row * width + feat_col + l]);
     }
 }
 
@@ -894,7 +897,7 @@ HF_API int hf_group_point_grad(int b, int n, int c, int m, int nsample, const fl
     return launch_status();
 }
 
-HF_API int hf_group_concat(int b, int n, int c, int m, int nsample, int width, const float *grouped_xyz,
+HF_API int hf_group_concat(int b, int n, int c, int m, int nsample, int width, int xyz_last, const float *grouped_xyz,
                            const float *points, const int *idx, float *out, hf_stream_t stream)
 {
     if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || width < 3 + c || width % 4 != 0) return HF_EINVAL;
@@ -903,12 +906,13 @@ HF_API int hf_group_concat(int b, int n, int c, int m, int nsample, int width, c
     if (!grouped_xyz || !points || !idx || !out || reinterpret_cast<uintptr_t>(out) % 16 != 0) return HF_EINVAL;
     const int block = 256;
     hipLaunchKernelGGL(group_concat_kernel, dim3(grid_for(nrows * (width / 4), block)), dim3(block), 0, as_stream(stream), n,
-                       c, width / 4, static_cast<long long>(m) * nsample, nrows, grouped_xyz, points, idx, out);
+                       c, width / 4, xyz_last ? c : 0, xyz_last ? 0 : 3, static_cast<long long>(m) * nsample, nrows, grouped_xyz,
+                       points, idx, out);
     return launch_status();
 }
 
-HF_API int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int width, const float *grad_out, const int *idx,
-                                float *grad_points, hf_stream_t stream)
+HF_API int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int width, int xyz_last, const float *grad_out,
+                                const int *idx, float *grad_points, hf_stream_t stream)
 {
     if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || width < 3 + c || !grad_points) return HF_EINVAL;
     if (b == 0) return HF_OK;
@@ -920,7 +924,7 @@ HF_API int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int wid
     if (!grad_out || !idx) return HF_EINVAL;
     const int block = 256;
     hipLaunchKernelGGL(group_concat_grad_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c, width,
-                       static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);
+                       xyz_last ? 0 : 3, static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);
     return launch_status();
 }
 

@@ -62,32 +62,33 @@ def group_point(points, idx):
 
 class _GroupConcat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points, idx, grouped_xyz, width):
+    def forward(ctx, points, idx, grouped_xyz, width, xyz_last):
         b, n, c = points.shape
         _, m, ns = idx.shape
         out = torch.empty((b, m, ns, width), dtype=torch.float32, device=points.device)
-        check(_lib.lib().hf_group_concat(b, n, c, m, ns, width, ptr(grouped_xyz), ptr(points), ptr(idx), ptr(out),
-                                         stream_ptr()), "group_concat")
+        check(_lib.lib().hf_group_concat(b, n, c, m, ns, width, int(xyz_last), ptr(grouped_xyz), ptr(points), ptr(idx),
+                                         ptr(out), stream_ptr()), "group_concat")
         ctx.save_for_backward(idx)
-        ctx.shape = (b, n, c, width)
+        ctx.shape = (b, n, c, width, int(xyz_last))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
-        b, n, c, width = ctx.shape
+        b, n, c, width, xyz_last = ctx.shape
         _, m, ns = idx.shape
         grad_out = grad_out.contiguous()
         g = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
-        check(_lib.lib().hf_group_concat_grad(b, n, c, m, ns, width, ptr(grad_out), ptr(idx), ptr(g), stream_ptr()),
-              "group_concat_grad")
-        return g, None, None, None
+        check(_lib.lib().hf_group_concat_grad(b, n, c, m, ns, width, xyz_last, ptr(grad_out), ptr(idx), ptr(g),
+                                              stream_ptr()), "group_concat_grad")
+        return g, None, None, None, None
 
 
-def group_concat(points, idx, grouped_xyz, width=None):
+def group_concat(points, idx, grouped_xyz, width=None, xyz_last=False):
     """[grouped_xyz, group_point(points, idx), zero padding] as one (B,M,K,width) tensor: the concat of
-    sample_and_group (pointnet_util.py:58-60) without the grouped temporary.  width defaults to 3 + C rounded up to
-    a multiple of 4.  Gradient w.r.t. points only (coordinates are inputs)."""
+    sample_and_group (pointnet_util.py:58-60) without the grouped temporary; xyz_last gives the multi-scale module's
+    order [features, xyz, padding] (pointnet_util.py:264).  width defaults to 3 + C rounded up to a multiple of 4.
+    Gradient w.r.t. points only (coordinates are inputs)."""
     points = dev_tensor(points, torch.float32, "points")
     idx = dev_tensor(idx, torch.int32, "idx")
     grouped_xyz = dev_tensor(grouped_xyz.detach(), torch.float32, "grouped_xyz")
@@ -98,7 +99,7 @@ def group_concat(points, idx, grouped_xyz, width=None):
     if width is None:
         width = (3 + c + 3) // 4 * 4
     require(width >= 3 + c and width % 4 == 0, "GroupConcat expects width >= 3 + c, a multiple of 4")
-    return _GroupConcat.apply(points, idx, grouped_xyz, width)
+    return _GroupConcat.apply(points, idx, grouped_xyz, width, bool(xyz_last))
 
 
 def query_ball_group(radius, nsample, xyz1, xyz2, center=True):

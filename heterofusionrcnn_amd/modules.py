@@ -227,13 +227,17 @@ class PointnetSAModuleMSG(nn.Module):
         outs = []
         for radius, nsample, mlp in zip(self.radius_list, self.nsample_list, self.mlps):
             idx, _, grouped_xyz = query_ball_group(radius, nsample, xyz, new_xyz, center=True)
-            if points is not None:
+            if points is not None and self.use_xyz and not xyz.requires_grad:
+                grouped = group_concat(points, idx, grouped_xyz, xyz_last=True)   # [features, xyz, 0-pad], one pass
+            elif points is not None:
                 grouped = group_point(points, idx)
                 if self.use_xyz:
                     grouped = torch.cat([grouped, grouped_xyz], dim=-1)
             else:
                 grouped = grouped_xyz
-            outs.append(mlp(grouped).max(dim=2).values)
+            bsz, npt, k, cin = grouped.shape
+            # the scale's MLP and the max over its K grouped points as one node (mlp.shared_mlp)
+            outs.append(shared_mlp(mlp, grouped.reshape(-1, cin), pool_k=k).reshape(bsz, npt, -1))
         return new_xyz, torch.cat(outs, dim=-1)
 
 

@@ -197,12 +197,13 @@ int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const
                    float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
 /* The concat of sample_and_group (pointnet_util.py:58-60) in one pass: out (b, m, nsample, width) rows are
- * [grouped_xyz (3), points[idx] (c), zeros]; width >= 3 + c, width % 4 == 0.  Replaces group_point + concat.
- * hf_group_concat_grad scatters the feature columns of grad_out back to grad_points (b, n, c). */
-int hf_group_concat(int b, int n, int c, int m, int nsample, int width, const float *grouped_xyz, const float *points,
-                    const int *idx, float *out, hf_stream_t stream);
-int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int width, const float *grad_out, const int *idx,
-                         float *grad_points, hf_stream_t stream);
+ * [grouped_xyz (3), points[idx] (c), zeros], or with xyz_last != 0 the multi-scale module's order
+ * [points[idx] (c), grouped_xyz (3), zeros] (pointnet_util.py:264); width >= 3 + c, width % 4 == 0.  Replaces
+ * group_point + concat.  hf_group_concat_grad scatters the feature columns of grad_out back to grad_points (b, n, c). */
+int hf_group_concat(int b, int n, int c, int m, int nsample, int width, int xyz_last, const float *grouped_xyz,
+                    const float *points, const int *idx, float *out, hf_stream_t stream);
+int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int width, int xyz_last, const float *grad_out,
+                         const int *idx, float *grad_points, hf_stream_t stream);
 
 /* three_nn (tf_interpolate.cpp:68-75) with a scratch buffer: the known points of every cloud are sorted along x
  * first, each query then sweeps outwards from its own x and stops as soon as (dx)^2 exceeds its third-best

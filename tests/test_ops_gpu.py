@@ -766,6 +766,13 @@ def test_group_concat_against_group_point_and_cat(hf, c):
     torch.testing.assert_close(p1.grad, p2.grad, rtol=1e-5, atol=1e-5)  # atomics: summation order differs
     with pytest.raises(ValueError):
         group_concat(pts, idx, gxyz, width=3 + c + 1 if (3 + c + 1) % 4 else 3 + c - 1)
+    # the multi-scale module's order: [features, xyz, padding]
+    p3 = pts.clone().requires_grad_(True); p4 = pts.clone().requires_grad_(True)
+    out2 = group_concat(p3, idx, gxyz, xyz_last=True)
+    ref2 = torch.cat([hf.group_point(p4, idx), gxyz], dim=-1)
+    assert torch.equal(out2[..., :3 + c], ref2) and bool((out2[..., 3 + c:] == 0).all())
+    out2.backward(g); ref2.backward(g[..., :3 + c].contiguous())
+    torch.testing.assert_close(p3.grad, p4.grad, rtol=1e-5, atol=1e-5)
 
 
 def test_sa_module_composition_against_oracle(hf, oracle_mod):
@@ -789,6 +796,24 @@ def test_sa_module_composition_against_oracle(hf, oracle_mod):
         w, b = msg.mlps[0][0].fc.weight, msg.mlps[0][0].fc.bias
         want = torch.relu(dev(np.concatenate([oracle_mod.group_point(feats, o_idx), o_gxyz], -1)) @ w.t() + b).max(dim=2).values
     torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+    # two scales with BatchNorm (training): fused [features, xyz, pad] rows + one node per scale, against the
+    # op-by-op form (group_point, cat, Linear, BatchNorm1d, relu, max) with the same weights; channel count 6 + 3 = 9
+    # is padded to 12 inside
+    torch.manual_seed(1)
+    feats6 = dev(np.random.default_rng(3).standard_normal((2, 1024, 6)).astype(np.float32))
+    msg2 = modules.PointnetSAModuleMSG(128, [0.2, 0.4], [16, 32], 6, [[8, 16], [8, 12]]).cuda()
+    _, out2 = msg2(dev(xyz), feats6)
+    assert out2.shape == (2, 128, 28)
+    new2 = hf.gather_point(dev(xyz), hf.farthest_point_sample(128, dev(xyz)))
+    refs = []
+    for radius, ns, mlp in zip([0.2, 0.4], [16, 32], msg2.mlps):
+        idx2, _, gx2 = hf.query_ball_group(radius, ns, dev(xyz), new2, center=True)
+        h = torch.cat([hf.group_point(feats6, idx2), gx2], dim=-1).reshape(-1, 9)
+        for layer in mlp:
+            bn = torch.nn.BatchNorm1d(layer.fc.out_features, eps=1e-3).cuda()
+            h = torch.relu(bn(torch.nn.functional.linear(h, layer.fc.weight, layer.fc.bias)))
+        refs.append(h.view(2, 128, ns, -1).max(dim=2).values)
+    torch.testing.assert_close(out2, torch.cat(refs, dim=-1), rtol=2e-4, atol=5e-5)
 
 
 def test_iou3d_and_nms_adapters(hf, oracle_mod):
