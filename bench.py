@@ -167,6 +167,9 @@ def per_op_table(hf, xyz):
     t["oriented_nms_9000_us"] = time_op(lambda: hf.oriented_nms(nb, 0.8), iters=5, warm=1)
     # kNN (PointCNN / knn-mode SA): K=8 neighbours of 4096 queries in 16384 points, no (B,M,N) matrix
     t["knn_k8_16384x4096_us"] = time_op(lambda: hf.knn_point(8, xyz, new_xyz), iters=10, warm=2)
+    t["knn_k8_16384x4096_all_pairs_us"] = time_op(lambda: hf.knn_point(8, xyz, new_xyz, all_pairs=True), iters=5, warm=1)
+    # the PointCNN RPN's neighbour search (rpn_multiclass.config: K=8 among all 16384 points of the cloud, pointfly.py:185-212)
+    t["knn_k8_16384x16384_us"] = time_op(lambda: hf.knn_point(8, xyz, xyz), iters=5, warm=1)
     # RoI crop at the RCNN shape: 64 boxes per frame, R=512, C=288 features (rcnn_multiclass.config:42,297)
     from heterofusionrcnn_amd import modules
     nroi = 64 * B

@@ -30,6 +30,8 @@ _SIGNATURES = {
     "hf_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "hf_knn_point": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "hf_knn_workspace": [_i, _i],
+    "hf_knn_point_sorted": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_select_top_k": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -82,6 +84,7 @@ _RESTYPES = {
     "hf_oriented_nms_workspace": _sz,
     "hf_bn_workspace": _sz,
     "hf_three_nn_workspace": _sz,
+    "hf_knn_workspace": _sz,
     "hf_linear_wgrad_workspace": _sz,
     "hf_linear_bn_fwd_workspace": _sz,
     "hf_linear_bn_bwd_workspace": _sz,

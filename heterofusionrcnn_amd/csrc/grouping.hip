@@ -838,6 +838,79 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
     return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// knn_point by a sweep over the data points sorted along x (same idea as three_nn's: interpolate.hip).
+// The tiled kernel above evaluates all n*m pairs (2.1 G for the 16384 x 16384 x 8 neighbour search of the PointCNN
+// RPN).  Sorted by x, a query binary-searches its own x and walks outwards; a side stops at the first point with
+// dx*dx > the current k-th best distance (fp32: dx*dx + dy*dy + dz*dz >= dx*dx, and |qx - x| is monotone along the
+// order).  Insertion compares (distance, index) lexicographically = ties to the lower index, the tiled kernel's rule.
+// The sorted cloud stays in global memory (L2-resident: 256 KB per cloud at n = 16384); the k best of each query
+// live in an LDS column per thread.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kKnnThreads) void knn_sweep_kernel(int n, int m, int k, const float *__restrict__ xyz2,
+                                                                const float4 *__restrict__ sorted,
+                                                                float *__restrict__ val, int *__restrict__ idx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *bd = reinterpret_cast<float *>(smem_raw);                       // k * kKnnThreads, column per thread
+    int *bi = reinterpret_cast<int *>(bd + static_cast<size_t>(k) * kKnnThreads);
+    const int t = threadIdx.x, bb = blockIdx.y;
+    const int j = blockIdx.x * kKnnThreads + t;
+    if (j >= m) return;
+    const float4 *src = sorted + static_cast<size_t>(bb) * n;
+    const float *q = xyz2 + (static_cast<size_t>(bb) * m + j) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    for (int s = 0; s < k; ++s) { bd[s * kKnnThreads + t] = INFINITY; bi[s * kKnnThreads + t] = 0x7fffffff; }
+    int lo = 0, hi = n;  // first position with x >= qx
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (src[mid].x < qx) lo = mid + 1; else hi = mid;
+    }
+    float worst = INFINITY;
+    int worst_i = 0x7fffffff;
+    auto visit = [&](const float4 c, float dx2) {
+        const float dy = qy - c.y, dz = qz - c.z;
+        const float d = dx2 + dy * dy + dz * dz;
+        const int ci = __float_as_int(c.w);
+        if (d < worst || (d == worst && ci < worst_i)) {
+            int pos = k - 1;
+            while (pos > 0) {
+                const float pd = bd[(pos - 1) * kKnnThreads + t];
+                const int pi = bi[(pos - 1) * kKnnThreads + t];
+                if (!(pd > d || (pd == d && pi > ci))) break;
+                bd[pos * kKnnThreads + t] = pd;
+                bi[pos * kKnnThreads + t] = pi;
+                --pos;
+            }
+            bd[pos * kKnnThreads + t] = d;
+            bi[pos * kKnnThreads + t] = ci;
+            worst = bd[(k - 1) * kKnnThreads + t];
+            worst_i = bi[(k - 1) * kKnnThreads + t];
+        }
+    };
+    int l = lo - 1, r = lo;
+    bool lgo = l >= 0, rgo = r < n;
+    while (lgo || rgo) {
+        if (rgo) {
+            const float4 c = src[r];
+            const float dx = qx - c.x;
+            const float dx2 = dx * dx;
+            if (dx2 > worst) rgo = false;
+            else { visit(c, dx2); rgo = ++r < n; }
+        }
+        if (lgo) {
+            const float4 c = src[l];
+            const float dx = qx - c.x;
+            const float dx2 = dx * dx;
+            if (dx2 > worst) lgo = false;
+            else { visit(c, dx2); lgo = --l >= 0; }
+        }
+    }
+    float *ov = val + (static_cast<size_t>(bb) * m + j) * k;
+    int *oi = idx + (static_cast<size_t>(bb) * m + j) * k;
+    for (int s = 0; s < k; ++s) { ov[s] = bd[s * kKnnThreads + t]; oi[s] = bi[s * kKnnThreads + t]; }
+}
+
 }  // namespace hf
 
 using namespace hf;
@@ -950,6 +1023,33 @@ HF_API int hf_knn_point(int b, int n, int m, int k, const float *xyz1, const flo
     else if (queries >= 64 * 1024) HF_KNN_LAUNCH(4);
     else HF_KNN_LAUNCH(16);
 #undef HF_KNN_LAUNCH
+    return launch_status();
+}
+
+HF_API size_t hf_knn_workspace(int b, int n)
+{
+    if (b <= 0 || n <= 0 || n > kSortByXMax) return 0;  // larger clouds use the tiled all-pairs kernel
+    return static_cast<size_t>(b) * n * sizeof(float4);
+}
+
+HF_API int hf_knn_point_sorted(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                               void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (k <= 0 || b < 0 || n <= 0 || m < 0 || k > n || !xyz1 || !xyz2 || !val || !idx) return HF_EINVAL;
+    if (b == 0 || m == 0) return HF_OK;
+    const size_t need = hf_knn_workspace(b, n);
+    if (need == 0) return hf_knn_point(b, n, m, k, xyz1, xyz2, val, idx, stream);
+    if (!workspace || workspace_bytes < need) return HF_EWORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0 || b > 65535) return HF_EINVAL;
+    const size_t lds = (sizeof(float) + sizeof(int)) * static_cast<size_t>(k) * kKnnThreads;
+    if (lds > 150 * 1024) return HF_EINVAL;  // k <= 75
+    hipStream_t st = as_stream(stream);
+    launch_sort_by_x(b, n, xyz1, workspace, st);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+    hipLaunchKernelGGL(knn_sweep_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, st, n, m, k, xyz2,
+                       static_cast<const float4 *>(workspace), val, idx);
     return launch_status();
 }
 

@@ -140,11 +140,12 @@ def select_top_k(k, dist):
     return outi, out
 
 
-def knn_point(k, xyz1, xyz2):
+def knn_point(k, xyz1, xyz2, all_pairs=False):
     """xyz1 (B,N,C) data, xyz2 (B,M,C) queries -> (val (B,M,k) squared L2 ascending, idx (B,M,k) int32).
     Reference: tf_grouping.py:62-95 (dense |q|^2 - 2 q.p^T + |p|^2 matrix + tf.nn.top_k).  For C == 3 this is
-    the HIP kNN kernel (no (B,M,N) matrix; ties: lower index first).  Other channel counts keep the reference's
-    three-term formula in torch."""
+    the HIP kNN kernel (no (B,M,N) matrix; ties: lower index first): data sorted along x + outward sweep for
+    N <= 16384, the tiled all-pairs kernel beyond that or with all_pairs=True.  Other channel counts keep the
+    reference's three-term formula in torch."""
     k = int(k)
     require(k > 0, "knn_point expects positive k")
     require(xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[0] == xyz2.shape[0] and
@@ -157,7 +158,14 @@ def knn_point(k, xyz1, xyz2):
         m = xyz2.shape[1]
         val = torch.empty((b, m, k), dtype=torch.float32, device=xyz1.device)
         idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
-        check(_lib.lib().hf_knn_point(b, n, m, k, ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), stream_ptr()), "knn_point")
+        L = _lib.lib()
+        nbytes = L.hf_knn_workspace(b, n)
+        if nbytes and not all_pairs:  # sorted-sweep kernels; larger clouds take the tiled all-pairs kernel
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=xyz1.device)
+            check(L.hf_knn_point_sorted(b, n, m, k, ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), ptr(ws), nbytes, stream_ptr()),
+                  "knn_point")
+        else:
+            check(L.hf_knn_point(b, n, m, k, ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), stream_ptr()), "knn_point")
         return val, idx
     r1 = (xyz1 * xyz1).sum(dim=2, keepdim=True)              # (b,n,1)
     r2 = (xyz2 * xyz2).sum(dim=2, keepdim=True)              # (b,m,1)

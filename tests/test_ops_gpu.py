@@ -896,6 +896,41 @@ def test_oracle_knn(hf, oracle_mod, b, n, m, k):
     assert np.array_equal(host(idx), oi)
     assert np.array_equal(host(val), ov)
     assert (np.diff(host(val), axis=-1) >= 0).all()
+    v2, i2 = hf.knn_point(k, dev(x1), dev(x2), all_pairs=True)      # the tiled all-pairs kernel: same answer
+    assert torch.equal(i2, idx) and torch.equal(v2, val)
+
+
+@pytest.mark.parametrize("kind", ["lattice", "same_x", "clustered", "k_equals_n", "max_sorted", "beyond_sorted"])
+def test_knn_sorted_sweep_matches_all_pairs_scan(hf, oracle_mod, kind):
+    """hf.knn_point sorts the data along x and sweeps outwards; it must give the tiled all-pairs kernel's answer bit
+    for bit (distances, and ties to the lower index) on inputs built to stress the sweep's stop rule"""
+    rng = np.random.default_rng(len(kind) + 3)
+    b, n, m, k = 2, 900, 2500, 8
+    if kind == "lattice":        # integer lattice: masses of exactly equal distances and equal x
+        x1 = rng.integers(0, 6, (b, n, 3)).astype(np.float32)
+        x2 = (rng.integers(0, 6, (b, m, 3)) + 0.5 * rng.integers(0, 2, (b, m, 3))).astype(np.float32)
+    elif kind == "same_x":       # no pruning possible along x
+        x1 = kitti_uniform(rng, b, n); x1[..., 0] = -7.5
+        x2 = kitti_uniform(rng, b, m)
+    elif kind == "clustered":
+        x1 = (rng.standard_normal((b, n, 3)) * 0.05).astype(np.float32) + np.float32(10)
+        x1[:, ::7] += 30
+        x2 = kitti_uniform(rng, b, m); x2[:, ::2] = (x1[:, rng.integers(0, n, m // 2)] + np.float32(1e-3)).astype(np.float32)
+    elif kind == "k_equals_n":
+        n, k = 40, 40
+        x1 = kitti_uniform(rng, b, n); x2 = kitti_uniform(rng, b, m)
+    elif kind == "max_sorted":
+        b, n, m, k = 1, 16384, 1500, 16
+        x1 = kitti_uniform(rng, b, n); x2 = kitti_uniform(rng, b, m)
+    else:                        # one more data point than the sort holds: the all-pairs kernel answers
+        b, n, m, k = 1, 16385, 300, 4
+        x1 = kitti_uniform(rng, b, n); x2 = kitti_uniform(rng, b, m)
+    val, idx = hf.knn_point(k, dev(x1), dev(x2))
+    v2, i2 = hf.knn_point(k, dev(x1), dev(x2), all_pairs=True)
+    assert torch.equal(idx, i2) and torch.equal(val, v2)
+    if n <= 1000:
+        ov, oi = oracle_mod.knn_point(k, x1, x2)
+        assert np.array_equal(host(idx), oi) and np.array_equal(host(val), ov)
 
 
 def test_sample_and_group_knn_mode(hf, oracle_mod):
