@@ -839,17 +839,129 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
 }
 
 // ------------------------------------------------------------------------------------------
-// knn_point by a sweep over the data points sorted along x (same idea as three_nn's: interpolate.hip).
+// knn_point on a 2-D grid with an outward ring search.
 // The tiled kernel above evaluates all n*m pairs (2.1 G for the 16384 x 16384 x 8 neighbour search of the PointCNN
-// RPN).  Sorted by x, a query binary-searches its own x and walks outwards; a side stops at the first point with
-// dx*dx > the current k-th best distance (fp32: dx*dx + dy*dy + dz*dz >= dx*dx, and |qx - x| is monotone along the
-// order).  Insertion compares (distance, index) lexicographically = ties to the lower index, the tiled kernel's rule.
-// The sorted cloud stays in global memory (L2-resident: 256 KB per cloud at n = 16384); the k best of each query
-// live in an LDS column per thread.
+// RPN).  Here the data points of a cloud are first binned into G x G cells over its two widest axes (counting sort
+// in LDS, one workgroup per cloud).  A query visits the cells at Chebyshev distance 0, 1, 2, ... from its own cell;
+// after ring R every unvisited point lies outside the (2R+1)^2 block of cells, i.e. at least `gap` away along one of
+// the two axes, where gap is the distance from the query to the nearest side of the block that still has cells
+// beyond it.  The search stops when (gap - margin)^2 > the current k-th best distance: fp32 d = dx^2 + dy^2 + dz^2
+// is >= each of its terms, and `margin` (1e-3 of a cell) covers the rounding of the cell assignment.  Insertion
+// compares (distance, index) lexicographically = ties to the lower index, the tiled kernel's rule, so the visiting
+// order does not matter.
+// Per-cloud workspace: float4 pts[n] (x, y, z, index) in cell order | int cellstart[G*G+1] | float params[8]
+// {amin, ascale, bmin, bscale, cell width a, cell width b, axis a, axis b}.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kKnnThreads) void knn_sweep_kernel(int n, int m, int k, const float *__restrict__ xyz2,
-                                                                const float4 *__restrict__ sorted,
-                                                                float *__restrict__ val, int *__restrict__ idx)
+constexpr int kKnnBinThreads = 1024;
+constexpr int kKnnMaxGrid = 64;          // G <= 64: 4096 cells of counters in LDS
+constexpr int kKnnBinMaxData = 65536;
+
+struct KnnWs {
+    float4 *pts;
+    int *cellstart;
+    float *params;
+};
+
+__host__ __device__ inline size_t knn_ws_stride(int n, int g)
+{
+    const size_t bytes = sizeof(float4) * static_cast<size_t>(n) + sizeof(int) * (static_cast<size_t>(g) * g + 1 + 8);
+    return (bytes + 15) / 16 * 16;
+}
+
+__device__ __forceinline__ KnnWs knn_ws(void *base, int frame, int n, int g)
+{
+    unsigned char *p = static_cast<unsigned char *>(base) + knn_ws_stride(n, g) * frame;
+    KnnWs w;
+    w.pts = reinterpret_cast<float4 *>(p);
+    w.cellstart = reinterpret_cast<int *>(w.pts + n);
+    w.params = reinterpret_cast<float *>(w.cellstart + g * g + 1);
+    return w;
+}
+
+// the same expression in the binning and in the search: monotone non-decreasing in v, NaN -> 0
+__device__ __forceinline__ int knn_cell1(float v, float vmin, float scale, int g)
+{
+    const float f = (v - vmin) * scale;
+    const int c = f >= 0.0f ? (f < 1.0e9f ? static_cast<int>(f) : g - 1) : 0;
+    return c > g - 1 ? g - 1 : c;
+}
+
+__global__ __launch_bounds__(kKnnBinThreads) void knn_bin_kernel(int n, int g, const float *__restrict__ xyz1,
+                                                                 void *__restrict__ workspace)
+{
+    __shared__ unsigned bmin[3], bmax[3];
+    __shared__ int wsum[16];
+    __shared__ int count[kKnnMaxGrid * kKnnMaxGrid];
+    const int t = threadIdx.x, lane = t & 63, bb = blockIdx.x;
+    const float *p = xyz1 + static_cast<size_t>(bb) * n * 3;
+    const KnnWs w = knn_ws(workspace, bb, n, g);
+    const int ncell = g * g;
+    if (t < 3) { bmin[t] = 0xffffffffu; bmax[t] = 0u; }
+    for (int c = t; c < ncell; c += kKnnBinThreads) count[c] = 0;
+    __syncthreads();
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int i = t; i < n; i += kKnnBinThreads) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = p[i * 3 + d];
+            if (fabsf(v) < INFINITY) { lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }  // the box of the finite coordinates
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const unsigned a = wave_min_u32(f2ord(lo[d])), b = wave_max_u32(f2ord(hi[d]));
+        if (lane == 0) { atomicMin(&bmin[d], a); atomicMax(&bmax[d], b); }
+    }
+    __syncthreads();
+    float ext[3], vmin[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        vmin[d] = ord2f(bmin[d]);
+        const float e = ord2f(bmax[d]) - vmin[d];
+        ext[d] = (e > 0.0f && e < INFINITY) ? e : 0.0f;  // no finite point on this axis / zero extent: one cell
+        if (!(fabsf(vmin[d]) < INFINITY)) vmin[d] = 0.0f;
+    }
+    // the two widest axes
+    int narrow = 0;
+    if (ext[1] < ext[narrow]) narrow = 1;
+    if (ext[2] < ext[narrow]) narrow = 2;
+    const int axa = narrow == 0 ? 1 : 0, axb = narrow == 2 ? 1 : 2;
+    const float sa = ext[axa] > 0.0f ? static_cast<float>(g) / ext[axa] : 0.0f;
+    const float sb = ext[axb] > 0.0f ? static_cast<float>(g) / ext[axb] : 0.0f;
+    auto cell_of = [&](int i) -> int {
+        return knn_cell1(p[i * 3 + axb], vmin[axb], sb, g) * g + knn_cell1(p[i * 3 + axa], vmin[axa], sa, g);
+    };
+    for (int i = t; i < n; i += kKnnBinThreads) atomicAdd(&count[cell_of(i)], 1);
+    __syncthreads();
+    int carry = 0;
+    for (int base = 0; base < ncell; base += kKnnBinThreads) {
+        const int c = base + t;
+        const int v = c < ncell ? count[c] : 0;
+        int tot;
+        const int ex = block_exclusive_scan(v, wsum, &tot);
+        if (c < ncell) {
+            w.cellstart[c] = carry + ex;
+            count[c] = carry + ex;  // becomes the scatter cursor
+        }
+        carry += tot;
+    }
+    if (t == 0) {
+        w.cellstart[ncell] = carry;
+        w.params[0] = vmin[axa]; w.params[1] = sa; w.params[2] = vmin[axb]; w.params[3] = sb;
+        w.params[4] = sa > 0.0f ? ext[axa] / static_cast<float>(g) : INFINITY;   // cell widths
+        w.params[5] = sb > 0.0f ? ext[axb] / static_cast<float>(g) : INFINITY;
+        w.params[6] = __int_as_float(axa); w.params[7] = __int_as_float(axb);
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += kKnnBinThreads) {
+        const int pos = atomicAdd(&count[cell_of(i)], 1);
+        w.pts[pos] = make_float4(p[i * 3], p[i * 3 + 1], p[i * 3 + 2], __int_as_float(i));
+    }
+}
+
+__global__ __launch_bounds__(kKnnThreads) void knn_grid_kernel(int n, int m, int k, int g, const float *__restrict__ xyz2,
+                                                               void *__restrict__ workspace, float *__restrict__ val,
+                                                               int *__restrict__ idx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *bd = reinterpret_cast<float *>(smem_raw);                       // k * kKnnThreads, column per thread
@@ -857,58 +969,82 @@ __global__ __launch_bounds__(kKnnThreads) void knn_sweep_kernel(int n, int m, in
     const int t = threadIdx.x, bb = blockIdx.y;
     const int j = blockIdx.x * kKnnThreads + t;
     if (j >= m) return;
-    const float4 *src = sorted + static_cast<size_t>(bb) * n;
+    const KnnWs w = knn_ws(workspace, bb, n, g);
     const float *q = xyz2 + (static_cast<size_t>(bb) * m + j) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     for (int s = 0; s < k; ++s) { bd[s * kKnnThreads + t] = INFINITY; bi[s * kKnnThreads + t] = 0x7fffffff; }
-    int lo = 0, hi = n;  // first position with x >= qx
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (src[mid].x < qx) lo = mid + 1; else hi = mid;
-    }
     float worst = INFINITY;
     int worst_i = 0x7fffffff;
-    auto visit = [&](const float4 c, float dx2) {
-        const float dy = qy - c.y, dz = qz - c.z;
-        const float d = dx2 + dy * dy + dz * dz;
-        const int ci = __float_as_int(c.w);
-        if (d < worst || (d == worst && ci < worst_i)) {
-            int pos = k - 1;
-            while (pos > 0) {
-                const float pd = bd[(pos - 1) * kKnnThreads + t];
-                const int pi = bi[(pos - 1) * kKnnThreads + t];
-                if (!(pd > d || (pd == d && pi > ci))) break;
-                bd[pos * kKnnThreads + t] = pd;
-                bi[pos * kKnnThreads + t] = pi;
-                --pos;
+    auto visit_cell = [&](int c) {
+        const int e = w.cellstart[c + 1];
+        for (int i = w.cellstart[c]; i < e; ++i) {
+            const float4 p = w.pts[i];
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const int ci = __float_as_int(p.w);
+            // an infinite distance never enters the list (the tiled kernel's strict `d < worst` against its +inf
+            // sentinel): such slots keep the sentinel index
+            if (d < worst || (d == worst && ci < worst_i && d < INFINITY)) {
+                int pos = k - 1;
+                while (pos > 0) {
+                    const float pd = bd[(pos - 1) * kKnnThreads + t];
+                    const int pi = bi[(pos - 1) * kKnnThreads + t];
+                    if (!(pd > d || (pd == d && pi > ci))) break;
+                    bd[pos * kKnnThreads + t] = pd;
+                    bi[pos * kKnnThreads + t] = pi;
+                    --pos;
+                }
+                bd[pos * kKnnThreads + t] = d;
+                bi[pos * kKnnThreads + t] = ci;
+                worst = bd[(k - 1) * kKnnThreads + t];
+                worst_i = bi[(k - 1) * kKnnThreads + t];
             }
-            bd[pos * kKnnThreads + t] = d;
-            bi[pos * kKnnThreads + t] = ci;
-            worst = bd[(k - 1) * kKnnThreads + t];
-            worst_i = bi[(k - 1) * kKnnThreads + t];
         }
     };
-    int l = lo - 1, r = lo;
-    bool lgo = l >= 0, rgo = r < n;
-    while (lgo || rgo) {
-        if (rgo) {
-            const float4 c = src[r];
-            const float dx = qx - c.x;
-            const float dx2 = dx * dx;
-            if (dx2 > worst) rgo = false;
-            else { visit(c, dx2); rgo = ++r < n; }
+    const float amin = w.params[0], sa = w.params[1], bmin = w.params[2], sb = w.params[3];
+    const float wa = w.params[4], wb = w.params[5];
+    const int axa = __float_as_int(w.params[6]), axb = __float_as_int(w.params[7]);
+    const float qa = axa == 0 ? qx : (axa == 1 ? qy : qz), qb = axb == 0 ? qx : (axb == 1 ? qy : qz);
+    const int ca = knn_cell1(qa, amin, sa, g), cb = knn_cell1(qb, bmin, sb, g);
+    const float margin_a = 1e-3f * wa, margin_b = 1e-3f * wb;
+    for (int ring = 0; ring < g; ++ring) {
+        const int a0 = ca - ring, a1 = ca + ring, b0 = cb - ring, b1 = cb + ring;
+        if (ring == 0) {
+            visit_cell(cb * g + ca);
+        } else {
+            // top and bottom rows of the ring, then the two side columns without their corners
+            for (int a = (a0 < 0 ? 0 : a0); a <= (a1 > g - 1 ? g - 1 : a1); ++a) {
+                if (b0 >= 0) visit_cell(b0 * g + a);
+                if (b1 <= g - 1) visit_cell(b1 * g + a);
+            }
+            for (int b = (b0 + 1 < 0 ? 0 : b0 + 1); b <= (b1 - 1 > g - 1 ? g - 1 : b1 - 1); ++b) {
+                if (a0 >= 0) visit_cell(b * g + a0);
+                if (a1 <= g - 1) visit_cell(b * g + a1);
+            }
         }
-        if (lgo) {
-            const float4 c = src[l];
-            const float dx = qx - c.x;
-            const float dx2 = dx * dx;
-            if (dx2 > worst) lgo = false;
-            else { visit(c, dx2); lgo = --l >= 0; }
-        }
+        // distance from the query to the nearest side of the visited block that still has cells beyond it
+        float gap = INFINITY;
+        if (a0 > 0) gap = fminf(gap, (qa - (amin + static_cast<float>(a0) * wa)) - margin_a);
+        if (a1 < g - 1) gap = fminf(gap, ((amin + static_cast<float>(a1 + 1) * wa) - qa) - margin_a);
+        if (b0 > 0) gap = fminf(gap, (qb - (bmin + static_cast<float>(b0) * wb)) - margin_b);
+        if (b1 < g - 1) gap = fminf(gap, ((bmin + static_cast<float>(b1 + 1) * wb) - qb) - margin_b);
+        if (gap == INFINITY) break;                       // the block covers the whole grid
+        if (gap > 0.0f && gap * gap > worst) break;       // nothing outside the block can enter the list
     }
     float *ov = val + (static_cast<size_t>(bb) * m + j) * k;
     int *oi = idx + (static_cast<size_t>(bb) * m + j) * k;
-    for (int s = 0; s < k; ++s) { ov[s] = bd[s * kKnnThreads + t]; oi[s] = bi[s * kKnnThreads + t]; }
+    for (int s = 0; s < k; ++s) {
+        const int id = bi[s * kKnnThreads + t];
+        ov[s] = bd[s * kKnnThreads + t];
+        oi[s] = id == 0x7fffffff ? 0 : id;  // an unfilled slot (all remaining distances infinite / NaN): index 0, as above
+    }
+}
+
+static int knn_grid_for(int n)
+{
+    int g = 4;
+    while (g < kKnnMaxGrid && g * g * 4 < n) g <<= 1;
+    return g;
 }
 
 }  // namespace hf
@@ -1028,8 +1164,8 @@ HF_API int hf_knn_point(int b, int n, int m, int k, const float *xyz1, const flo
 
 HF_API size_t hf_knn_workspace(int b, int n)
 {
-    if (b <= 0 || n <= 0 || n > kSortByXMax) return 0;  // larger clouds use the tiled all-pairs kernel
-    return static_cast<size_t>(b) * n * sizeof(float4);
+    if (b <= 0 || n <= 0 || n > kKnnBinMaxData) return 0;  // larger clouds use the tiled all-pairs kernel
+    return knn_ws_stride(n, knn_grid_for(n)) * static_cast<size_t>(b);
 }
 
 HF_API int hf_knn_point_sorted(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
@@ -1044,12 +1180,13 @@ HF_API int hf_knn_point_sorted(int b, int n, int m, int k, const float *xyz1, co
     const size_t lds = (sizeof(float) + sizeof(int)) * static_cast<size_t>(k) * kKnnThreads;
     if (lds > 150 * 1024) return HF_EINVAL;  // k <= 75
     hipStream_t st = as_stream(stream);
-    launch_sort_by_x(b, n, xyz1, workspace, st);
+    const int g = knn_grid_for(n);
+    hipLaunchKernelGGL(knn_bin_kernel, dim3(b), dim3(kKnnBinThreads), 0, st, n, g, xyz1, workspace);
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds));
-    hipLaunchKernelGGL(knn_sweep_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, st, n, m, k, xyz2,
-                       static_cast<const float4 *>(workspace), val, idx);
+    hipLaunchKernelGGL(knn_grid_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, st, n, m, k, g, xyz2,
+                       workspace, val, idx);
     return launch_status();
 }
 

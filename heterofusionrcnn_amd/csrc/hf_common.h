@@ -30,11 +30,6 @@ void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *part
 // mlp.hip: fp64 reduction of BN-backward partials (sum dh, sum dh*xhat) -> dbeta, dgamma
 void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma, float *dbeta, hipStream_t st);
 
-// interpolate.hip: the points of every cloud as float4 (x, y, z, original index) in ascending x (bitonic sort in LDS,
-// one workgroup per cloud); n <= kSortByXMax
-constexpr int kSortByXMax = 16384;
-void launch_sort_by_x(int b, int n, const float *pts, void *sorted_float4, hipStream_t st);
-
 // status of the launch that was just enqueued (no synchronisation)
 inline int launch_status() { return hip_status(hipGetLastError()); }
 

@@ -531,21 +531,6 @@ static int nn_pow2_at_least(int m)
     return p;
 }
 
-namespace hf {
-void launch_sort_by_x(int b, int n, const float *pts, void *sorted_float4, hipStream_t st)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&three_nn_sort_known_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(unsigned long long)) * kSortByXMax);
-        attr_done = true;
-    }
-    const int npad = nn_pow2_at_least(n);
-    hipLaunchKernelGGL(three_nn_sort_known_kernel, dim3(b), dim3(kNnSortThreads), sizeof(unsigned long long) * static_cast<size_t>(npad),
-                       st, n, npad, pts, static_cast<float4 *>(sorted_float4));
-}
-}  // namespace hf
-
 HF_API size_t hf_three_nn_workspace(int b, int m)
 {
     if (b <= 0 || m <= 0 || m > kNnSweepMaxKnown) return 0;  // larger clouds use the brute-force kernel
@@ -567,11 +552,15 @@ HF_API int hf_three_nn_sorted(int b, int n, int m, const float *unknown, const f
     const size_t sweep_lds = sizeof(float4) * static_cast<size_t>(m);
     static bool attr_done = false;
     if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&three_nn_sort_known_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&three_nn_sweep_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_done = true;
     }
-    launch_sort_by_x(b, m, known, sorted, st);
+    const int mpad = nn_pow2_at_least(m);
+    hipLaunchKernelGGL(three_nn_sort_known_kernel, dim3(b), dim3(kNnSortThreads), sizeof(unsigned long long) * static_cast<size_t>(mpad),
+                       st, m, mpad, known, sorted);
     hipLaunchKernelGGL(three_nn_sweep_kernel, dim3(div_up(n, kNnThreads), b), dim3(kNnThreads), sweep_lds, st, n, m,
                        unknown, sorted, dist2, idx);
     return launch_status();

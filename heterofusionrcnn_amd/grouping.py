@@ -143,8 +143,8 @@ def select_top_k(k, dist):
 def knn_point(k, xyz1, xyz2, all_pairs=False):
     """xyz1 (B,N,C) data, xyz2 (B,M,C) queries -> (val (B,M,k) squared L2 ascending, idx (B,M,k) int32).
     Reference: tf_grouping.py:62-95 (dense |q|^2 - 2 q.p^T + |p|^2 matrix + tf.nn.top_k).  For C == 3 this is
-    the HIP kNN kernel (no (B,M,N) matrix; ties: lower index first): data sorted along x + outward sweep for
-    N <= 16384, the tiled all-pairs kernel beyond that or with all_pairs=True.  Other channel counts keep the
+    the HIP kNN kernel (no (B,M,N) matrix; ties: lower index first): data binned into a 2-D grid + ring search for
+    N <= 65536, the tiled all-pairs kernel beyond that or with all_pairs=True.  Other channel counts keep the
     reference's three-term formula in torch."""
     k = int(k)
     require(k > 0, "knn_point expects positive k")
@@ -160,7 +160,7 @@ def knn_point(k, xyz1, xyz2, all_pairs=False):
         idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
         L = _lib.lib()
         nbytes = L.hf_knn_workspace(b, n)
-        if nbytes and not all_pairs:  # sorted-sweep kernels; larger clouds take the tiled all-pairs kernel
+        if nbytes and not all_pairs:  # grid ring-search kernels; larger clouds take the tiled all-pairs kernel
             ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=xyz1.device)
             check(L.hf_knn_point_sorted(b, n, m, k, ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), ptr(ws), nbytes, stream_ptr()),
                   "knn_point")

@@ -196,10 +196,10 @@ int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const
                    const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                    float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
-/* knn_point (see hf_knn_point) with a scratch buffer: the data points of every cloud are sorted along x first, each
- * query then sweeps outwards from its own x and stops a side once dx^2 exceeds its k-th best distance.  Same outputs
- * as hf_knn_point (ties to the lower index).  hf_knn_workspace returns 0 when n is beyond the sort's LDS capacity
- * (16384 points); hf_knn_point_sorted then runs hf_knn_point. */
+/* knn_point (see hf_knn_point) with a scratch buffer: the data points of every cloud are binned into a 2-D grid over
+ * its two widest axes first; each query then searches rings of cells around its own and stops once everything outside
+ * the visited block is provably farther than its k-th best distance.  Same outputs as hf_knn_point (ties to the lower
+ * index).  hf_knn_workspace returns 0 for n > 65536; hf_knn_point_sorted then runs hf_knn_point. */
 size_t hf_knn_workspace(int b, int n);
 int hf_knn_point_sorted(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
                         void *workspace, size_t workspace_bytes, hf_stream_t stream);

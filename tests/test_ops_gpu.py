@@ -902,8 +902,8 @@ def test_oracle_knn(hf, oracle_mod, b, n, m, k):
 
 @pytest.mark.parametrize("kind", ["lattice", "same_x", "clustered", "k_equals_n", "max_sorted", "beyond_sorted"])
 def test_knn_sorted_sweep_matches_all_pairs_scan(hf, oracle_mod, kind):
-    """hf.knn_point sorts the data along x and sweeps outwards; it must give the tiled all-pairs kernel's answer bit
-    for bit (distances, and ties to the lower index) on inputs built to stress the sweep's stop rule"""
+    """hf.knn_point bins the data into a 2-D grid and searches rings of cells; it must give the tiled all-pairs kernel's
+    answer bit for bit (distances, and ties to the lower index) on inputs built to stress the search's stop rule"""
     rng = np.random.default_rng(len(kind) + 3)
     b, n, m, k = 2, 900, 2500, 8
     if kind == "lattice":        # integer lattice: masses of exactly equal distances and equal x
@@ -922,12 +922,16 @@ def test_knn_sorted_sweep_matches_all_pairs_scan(hf, oracle_mod, kind):
     elif kind == "max_sorted":
         b, n, m, k = 1, 16384, 1500, 16
         x1 = kitti_uniform(rng, b, n); x2 = kitti_uniform(rng, b, m)
-    else:                        # one more data point than the sort holds: the all-pairs kernel answers
-        b, n, m, k = 1, 16385, 300, 4
+    else:                        # one more data point than the binned path takes: the all-pairs kernel answers
+        b, n, m, k = 1, 65537, 300, 4
         x1 = kitti_uniform(rng, b, n); x2 = kitti_uniform(rng, b, m)
+        x2[0, :5] = [[1e6, 0, 0], [-1e6, 0, 0], [np.nan, 0, 0], [0, np.inf, 0], [0, 0, 0]]   # queries far outside / non-finite
+    if kind == "max_sorted":
+        x2[0, :3] = [[1e6, 0, 0], [-1e6, 0, 0], [0, 1e30, 0]]           # queries far outside the data's x range
+        x1[0, :4, 0] = [np.inf, -np.inf, np.nan, 3e38]                   # non-finite / huge data coordinates
     val, idx = hf.knn_point(k, dev(x1), dev(x2))
     v2, i2 = hf.knn_point(k, dev(x1), dev(x2), all_pairs=True)
-    assert torch.equal(idx, i2) and torch.equal(val, v2)
+    assert torch.equal(idx, i2) and np.array_equal(host(val), host(v2), equal_nan=True)
     if n <= 1000:
         ov, oi = oracle_mod.knn_point(k, x1, x2)
         assert np.array_equal(host(idx), oi) and np.array_equal(host(val), ov)
