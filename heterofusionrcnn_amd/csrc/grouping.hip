@@ -1162,10 +1162,32 @@ HF_API int hf_knn_point(int b, int n, int m, int k, const float *xyz1, const flo
     return launch_status();
 }
 
+namespace hf {
+size_t knn_grid_workspace(int b, int n)
+{
+    if (b <= 0 || n <= 0 || n > kKnnBinMaxData) return 0;
+    return knn_ws_stride(n, knn_grid_for(n)) * static_cast<size_t>(b);
+}
+
+int launch_knn_grid(int b, int n, int m, int k, const float *data, const float *queries, float *val, int *idx,
+                    void *workspace, hipStream_t st)
+{
+    const size_t lds = (sizeof(float) + sizeof(int)) * static_cast<size_t>(k) * kKnnThreads;
+    if (lds > 150 * 1024 || b > 65535 || reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return HF_EINVAL;  // k <= 75
+    const int g = knn_grid_for(n);
+    hipLaunchKernelGGL(knn_bin_kernel, dim3(b), dim3(kKnnBinThreads), 0, st, n, g, data, workspace);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+    hipLaunchKernelGGL(knn_grid_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, st, n, m, k, g, queries,
+                       workspace, val, idx);
+    return launch_status();
+}
+}  // namespace hf
+
 HF_API size_t hf_knn_workspace(int b, int n)
 {
-    if (b <= 0 || n <= 0 || n > kKnnBinMaxData) return 0;  // larger clouds use the tiled all-pairs kernel
-    return knn_ws_stride(n, knn_grid_for(n)) * static_cast<size_t>(b);
+    return knn_grid_workspace(b, n);  // 0: larger clouds use the tiled all-pairs kernel
 }
 
 HF_API int hf_knn_point_sorted(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
@@ -1176,18 +1198,7 @@ HF_API int hf_knn_point_sorted(int b, int n, int m, int k, const float *xyz1, co
     const size_t need = hf_knn_workspace(b, n);
     if (need == 0) return hf_knn_point(b, n, m, k, xyz1, xyz2, val, idx, stream);
     if (!workspace || workspace_bytes < need) return HF_EWORKSPACE;
-    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0 || b > 65535) return HF_EINVAL;
-    const size_t lds = (sizeof(float) + sizeof(int)) * static_cast<size_t>(k) * kKnnThreads;
-    if (lds > 150 * 1024) return HF_EINVAL;  // k <= 75
-    hipStream_t st = as_stream(stream);
-    const int g = knn_grid_for(n);
-    hipLaunchKernelGGL(knn_bin_kernel, dim3(b), dim3(kKnnBinThreads), 0, st, n, g, xyz1, workspace);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
-    hipLaunchKernelGGL(knn_grid_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, st, n, m, k, g, xyz2,
-                       workspace, val, idx);
-    return launch_status();
+    return launch_knn_grid(b, n, m, k, xyz1, xyz2, val, idx, workspace, as_stream(stream));
 }
 
 HF_API int hf_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, float *out, hf_stream_t stream)

@@ -30,6 +30,12 @@ void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *part
 // mlp.hip: fp64 reduction of BN-backward partials (sum dh, sum dh*xhat) -> dbeta, dgamma
 void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma, float *dbeta, hipStream_t st);
 
+// grouping.hip: k nearest data points of every query on a 2-D grid (binning + ring search), any k <= 75; fewer than k
+// data points leave (+inf, index 0) in the unfilled slots.  workspace: knn_grid_workspace(b, n) bytes, 16-byte aligned.
+size_t knn_grid_workspace(int b, int n);
+int launch_knn_grid(int b, int n, int m, int k, const float *data, const float *queries, float *val, int *idx,
+                    void *workspace, hipStream_t st);
+
 // status of the launch that was just enqueued (no synchronisation)
 inline int launch_status() { return hip_status(hipGetLastError()); }
 

@@ -62,124 +62,6 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(int n, int m, cons
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// three_nn by a sweep over the known points sorted along x.
-// The brute-force kernel above evaluates all n*m pairs (537 M for 16384 x 4096 x 8 clouds).  Sorted by x, a
-// query only has to visit the known points with (ux - x)^2 <= its current third-best distance: in fp32
-// d = dx*dx + dy*dy + dz*dz >= dx*dx (adding non-negative terms never rounds below the first), and |ux - x|
-// is monotone along the sorted order, so the first point on either side with dx*dx > b3 ends that side.
-// Visiting order is no longer ascending index, so insertion compares (distance, index) lexicographically --
-// the order the reference's strict `<` over ascending k produces (tf_interpolate_g.cu:43-62).
-// Step 1: one workgroup per cloud sorts (x, index) keys with a bitonic network in LDS and writes the known
-// points as float4 (x, y, z, index) in that order.  Step 2: 256 queries per workgroup, sorted cloud in LDS.
-// ------------------------------------------------------------------------------------------
-constexpr int kNnSortThreads = 1024;
-constexpr int kNnSweepMaxKnown = 8192;  // 128 KB of LDS as float4
-
-__global__ __launch_bounds__(kNnSortThreads) void three_nn_sort_known_kernel(int m, int mpad,
-                                                                             const float *__restrict__ known,
-                                                                             float4 *__restrict__ sorted)
-{
-    extern __shared__ unsigned long long nn_keys[];
-    const int t = threadIdx.x, bb = blockIdx.x;
-    const float *kn = known + static_cast<size_t>(bb) * m * 3;
-    for (int i = t; i < mpad; i += kNnSortThreads)
-        nn_keys[i] = i < m ? (static_cast<unsigned long long>(f2ord(kn[i * 3])) << 32) | static_cast<unsigned>(i) : ~0ull;
-    __syncthreads();
-    for (int size = 2; size <= mpad; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int p = t; p < (mpad >> 1); p += kNnSortThreads) {
-                const int lo = ((p / stride) * stride << 1) + (p % stride);
-                const int hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned long long a = nn_keys[lo], b = nn_keys[hi];
-                if ((a > b) == up) { nn_keys[lo] = b; nn_keys[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    float4 *out = sorted + static_cast<size_t>(bb) * m;
-    for (int i = t; i < m; i += kNnSortThreads) {
-        const int k = static_cast<int>(nn_keys[i] & 0xffffffffu);
-        out[i] = make_float4(kn[k * 3], kn[k * 3 + 1], kn[k * 3 + 2], __int_as_float(k));
-    }
-}
-
-struct Best3 {
-    float b1, b2, b3;
-    int i1, i2, i3;
-};
-
-__device__ __forceinline__ bool nn_before(float d, int k, float bd, int bi) { return d < bd || (d == bd && k < bi); }
-
-__device__ __forceinline__ void nn_insert(Best3 &s, float d, int k)
-{
-    if (!nn_before(d, k, s.b3, s.i3)) return;
-    if (nn_before(d, k, s.b1, s.i1)) {
-        s.b3 = s.b2; s.i3 = s.i2;
-        s.b2 = s.b1; s.i2 = s.i1;
-        s.b1 = d; s.i1 = k;
-    } else if (nn_before(d, k, s.b2, s.i2)) {
-        s.b3 = s.b2; s.i3 = s.i2;
-        s.b2 = d; s.i2 = k;
-    } else {
-        s.b3 = d; s.i3 = k;
-    }
-}
-
-__global__ __launch_bounds__(kNnThreads) void three_nn_sweep_kernel(int n, int m, const float *__restrict__ unknown,
-                                                                    const float4 *__restrict__ sorted,
-                                                                    float *__restrict__ dist2, int *__restrict__ idx)
-{
-    extern __shared__ float4 nn_cloud[];
-    const int t = threadIdx.x, bb = blockIdx.y;
-    const float4 *src = sorted + static_cast<size_t>(bb) * m;
-    for (int i = t; i < m; i += kNnThreads) nn_cloud[i] = src[i];
-    __syncthreads();
-    const int j = blockIdx.x * kNnThreads + t;
-    if (j >= n) return;
-    const float *u = unknown + (static_cast<size_t>(bb) * n + j) * 3;
-    const float ux = u[0], uy = u[1], uz = u[2];
-    int lo = 0, hi = m;  // first position with x >= ux
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (nn_cloud[mid].x < ux) lo = mid + 1; else hi = mid;
-    }
-    // the initial index 0 with an infinite distance is what the reference leaves when m < 3; a candidate at
-    // distance +inf must not displace it, which nn_before guarantees only for k >= 0 == i: fine, k >= 0
-    Best3 s = { INFINITY, INFINITY, INFINITY, 0, 0, 0 };
-    int l = lo - 1, r = lo;
-    bool lgo = l >= 0, rgo = r < m;
-    while (lgo || rgo) {
-        if (rgo) {
-            const float4 c = nn_cloud[r];
-            const float dx = ux - c.x, dy = uy - c.y, dz = uz - c.z;
-            const float dx2 = dx * dx;
-            if (dx2 > s.b3) {
-                rgo = false;
-            } else {
-                nn_insert(s, dx2 + dy * dy + dz * dz, __float_as_int(c.w));
-                rgo = ++r < m;
-            }
-        }
-        if (lgo) {
-            const float4 c = nn_cloud[l];
-            const float dx = ux - c.x, dy = uy - c.y, dz = uz - c.z;
-            const float dx2 = dx * dx;
-            if (dx2 > s.b3) {
-                lgo = false;
-            } else {
-                nn_insert(s, dx2 + dy * dy + dz * dz, __float_as_int(c.w));
-                lgo = --l >= 0;
-            }
-        }
-    }
-    float *od = dist2 + (static_cast<size_t>(bb) * n + j) * 3;
-    int *oi = idx + (static_cast<size_t>(bb) * n + j) * 3;
-    od[0] = s.b1; od[1] = s.b2; od[2] = s.b3;
-    oi[0] = s.i1; oi[1] = s.i2; oi[2] = s.i3;
-}
-
 // channel-first op layout: points (b,c,m) -> out (b,c,n)   (tf_interpolate_g.cu:90-110)
 __global__ void three_interpolate_cf_kernel(int c, int m, int n, const float *__restrict__ points,
                                             const int *__restrict__ idx, const float *__restrict__ weight,
@@ -524,19 +406,14 @@ static int interpolate_grad_gather(int b, int n, int c, int ld, int m, const flo
     return launch_status();
 }
 
-static int nn_pow2_at_least(int m)
-{
-    int p = 2;
-    while (p < m) p <<= 1;
-    return p;
-}
-
 HF_API size_t hf_three_nn_workspace(int b, int m)
 {
-    if (b <= 0 || m <= 0 || m > kNnSweepMaxKnown) return 0;  // larger clouds use the brute-force kernel
-    return static_cast<size_t>(b) * m * sizeof(float4);
+    return knn_grid_workspace(b, m);  // 0: larger clouds use the all-pairs kernel
 }
 
+// three_nn IS the 3-nearest-neighbour search with the reference's conventions: squared distances ascending, ties to
+// the lower index (strict `<` over ascending k, tf_interpolate_g.cu:43-62), +inf / index 0 in the slots that fewer
+// than three known points leave empty -- exactly what the grid kNN kernel (grouping.hip) produces for k = 3.
 HF_API int hf_three_nn_sorted(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                               void *workspace, size_t workspace_bytes, hf_stream_t stream)
 {
@@ -546,24 +423,7 @@ HF_API int hf_three_nn_sorted(int b, int n, int m, const float *unknown, const f
     const size_t need = hf_three_nn_workspace(b, m);
     if (need == 0) return hf_three_nn(b, n, m, unknown, known, dist2, idx, stream);
     if (!workspace || workspace_bytes < need) return HF_EWORKSPACE;
-    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return HF_EINVAL;
-    hipStream_t st = as_stream(stream);
-    float4 *sorted = static_cast<float4 *>(workspace);
-    const size_t sweep_lds = sizeof(float4) * static_cast<size_t>(m);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&three_nn_sort_known_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&three_nn_sweep_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_done = true;
-    }
-    const int mpad = nn_pow2_at_least(m);
-    hipLaunchKernelGGL(three_nn_sort_known_kernel, dim3(b), dim3(kNnSortThreads), sizeof(unsigned long long) * static_cast<size_t>(mpad),
-                       st, m, mpad, known, sorted);
-    hipLaunchKernelGGL(three_nn_sweep_kernel, dim3(div_up(n, kNnThreads), b), dim3(kNnThreads), sweep_lds, st, n, m,
-                       unknown, sorted, dist2, idx);
-    return launch_status();
+    return launch_knn_grid(b, m, n, 3, known, unknown, dist2, idx, workspace, as_stream(stream));
 }
 
 HF_API int hf_three_interpolate_cl_grad_gather(int b, int n, int c, int m, const float *grad_out, const float *weight,

@@ -20,7 +20,7 @@ def three_nn(xyz1, xyz2):
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
     L = _lib.lib()
     nbytes = L.hf_three_nn_workspace(b, m)
-    if nbytes:  # sorted-sweep kernels; larger clouds take the all-pairs kernel
+    if nbytes:  # grid ring-search kernels (the k = 3 case of knn_point); larger clouds take the all-pairs kernel
         ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=xyz1.device)
         check(L.hf_three_nn_sorted(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), ptr(ws), nbytes, stream_ptr()),
               "three_nn")

@@ -213,10 +213,10 @@ int hf_group_concat(int b, int n, int c, int m, int nsample, int width, int xyz_
 int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int width, int xyz_last, const float *grad_out,
                          const int *idx, float *grad_points, hf_stream_t stream);
 
-/* three_nn (tf_interpolate.cpp:68-75) with a scratch buffer: the known points of every cloud are sorted along x
- * first, each query then sweeps outwards from its own x and stops as soon as (dx)^2 exceeds its third-best
- * distance.  Same outputs as hf_three_nn, bit for bit (ties to the lower index).  hf_three_nn_workspace returns
- * 0 when m is too large for the sorted cloud to sit in LDS; hf_three_nn_sorted then runs hf_three_nn. */
+/* three_nn (tf_interpolate.cpp:68-75) with a scratch buffer: the known points of every cloud are binned into a 2-D
+ * grid first, each unknown point then searches rings of cells around its own (the k = 3 case of hf_knn_point_sorted).
+ * Same outputs as hf_three_nn, bit for bit (ties to the lower index, +inf / 0 when fewer than 3 known points).
+ * hf_three_nn_workspace returns 0 for m > 65536; hf_three_nn_sorted then runs hf_three_nn. */
 size_t hf_three_nn_workspace(int b, int m);
 int hf_three_nn_sorted(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                        void *workspace, size_t workspace_bytes, hf_stream_t stream);

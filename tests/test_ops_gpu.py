@@ -284,8 +284,9 @@ def test_oracle_three_nn(hf, oracle_mod, b, n, m):
 
 @pytest.mark.parametrize("kind", ["lattice", "same_x", "clustered", "two_known", "nonfinite", "max_lds", "beyond_lds"])
 def test_three_nn_sorted_sweep_matches_all_pairs_scan(hf, oracle_mod, kind):
-    """hf.three_nn sorts the known points along x and sweeps outwards; it must give the all-pairs scan's answer
-    bit for bit (distances, and ties to the lower index) on inputs built to stress the sweep's stop rule"""
+    """hf.three_nn bins the known points into a 2-D grid and searches rings of cells (the k = 3 case of the kNN
+    kernel); it must give the all-pairs scan's answer bit for bit (distances, and ties to the lower index) on inputs
+    built to stress the search's stop rule"""
     from heterofusionrcnn_amd.interpolate import three_nn_all_pairs
     rng = np.random.default_rng(len(kind))
     b, n, m = 2, 3000, 700
@@ -308,7 +309,7 @@ def test_three_nn_sorted_sweep_matches_all_pairs_scan(hf, oracle_mod, kind):
     elif kind == "max_lds":
         b, n, m = 1, 2000, 8192
         k = kitti_uniform(rng, b, m); u = kitti_uniform(rng, b, n)
-    else:                        # one more known point than the sweep handles: the all-pairs kernel answers
+    else:                        # a cloud larger than the former LDS limit: the grid path handles it too
         b, n, m = 1, 500, 8193
         k = kitti_uniform(rng, b, m); u = kitti_uniform(rng, b, n)
     dist, idx = hf.three_nn(dev(u), dev(k))
