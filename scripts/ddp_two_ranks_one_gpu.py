@@ -1,0 +1,66 @@
+"""Two data-parallel ranks sharing ONE GPU (gloo backend, CUDA tensors): the real SA/FP stack with its fused autograd
+nodes under DistributedDataParallel.  Each rank trains on its own frames; after one step the averaged gradients and the
+updated weights must equal a single-process run over both shards (mean of the two per-shard gradients), and both ranks
+must hold identical weights.  RCCL itself needs one GPU per rank; this exercises everything else of the N > 1 path
+(DDP hooks on the fused nodes, zero bias gradients, grouped geometry prefetch) on the 1-GPU box.
+Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P scripts/ddp_two_ranks_one_gpu.py"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from heterofusionrcnn_amd import modules
+from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
+from bench import kitti_uniform
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+SA = ((512, 1.0, 16, (16, 32)), (128, 2.0, 16, (32, 64)))
+FP = ((64, 64), (32, 32))
+
+
+def make():
+    torch.manual_seed(11)
+    return modules.PointnetSAFPStack(in_channel=1, sa=SA, fp=FP).cuda()
+
+
+def batch(r):
+    rng = np.random.default_rng(100 + r)
+    return (torch.from_numpy(kitti_uniform(rng, 2, 4096)).cuda(),
+            torch.from_numpy(rng.uniform(-.5, .5, (2, 4096, 1)).astype(np.float32)).cuda())
+
+
+model = make()
+if rank == 1:                       # de-synchronise on purpose: DDP must broadcast rank 0's weights
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.5)
+net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
+opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+xyz, inten = batch(rank)
+pf = GeometryPrefetcher(model.geometry, depth=2, group=1)
+pf.submit(xyz)
+opt.zero_grad(set_to_none=True)
+net(xyz, inten, geometry=pf.get()).mean().backward()
+grads = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+opt.step()
+weights = torch.cat([p.detach().flatten() for p in model.parameters()])
+both = [torch.empty_like(weights) for _ in range(world)]
+dist.all_gather(both, weights)
+ok = True
+if rank == 0:
+    assert torch.equal(both[0], both[1]), "ranks diverged"
+    ref = make()
+    per = []
+    for r in range(world):          # single process: the mean of the per-shard gradients
+        ref.zero_grad(set_to_none=True)
+        ref(*batch(r)).mean().backward()
+        per.append(torch.cat([p.grad.flatten() for p in ref.parameters()]).clone())
+    want = (per[0] + per[1]) / 2
+    # a pre-activation within rounding of zero may fall on the other side of the ReLU (see the chain test): relative bound
+    err = (grads - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+    print("max relative gradient difference vs single process: %.3e" % err)
+    ok = err < 2e-3 and bool(torch.isfinite(weights).all())
+    print("TWO_RANK_OK" if ok else "TWO_RANK_FAIL")
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
