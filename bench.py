@@ -288,7 +288,7 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="run the geometry ops inline instead of one step ahead")
     ap.add_argument("--prefetch-depth", type=int, default=2, help="batches of geometry in flight (one HIP stream each)")
     ap.add_argument("--prefetch-group", type=int, default=0,
-                    help="batches whose geometry is computed in one launch (0 = the largest divisor of --steps up to 8, "
+                    help="batches whose geometry is computed in one launch (0 = the largest divisor of --steps up to 16, "
                          "so that the timed steps contain exactly as many geometry launches as they consume)")
     ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()

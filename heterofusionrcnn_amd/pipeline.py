@@ -22,7 +22,7 @@ def _walk(obj, fn):
             _walk(v, fn)
 
 
-def choose_group(steps, largest=8):
+def choose_group(steps, largest=16):
     """batches per geometry launch for a run of `steps` timed steps: the largest divisor of `steps` up to `largest`,
     so that the run launches the geometry of exactly as many batches as it consumes"""
     steps = int(steps)

@@ -7,9 +7,10 @@ from heterofusionrcnn_amd.pipeline import _slice_frames, _walk, choose_group
 def test_choose_group_divides_the_run():
     for steps in range(1, 200):
         g = choose_group(steps)
-        assert 1 <= g <= 8 and steps % g == 0
-        assert all(steps % h for h in range(g + 1, 9))
-    assert choose_group(10) == 5 and choose_group(16) == 8 and choose_group(7) == 7 and choose_group(11) == 1
+        assert 1 <= g <= 16 and steps % g == 0
+        assert all(steps % h for h in range(g + 1, 17))
+    assert choose_group(10) == 10 and choose_group(16) == 16 and choose_group(7) == 7 and choose_group(17) == 1
+    assert choose_group(20) == 10 and choose_group(50) == 10 and choose_group(100) == 10
     assert choose_group(0) == 1
 
 
