@@ -273,16 +273,14 @@ def cpu_baseline(frames):
     return res
 
 
-def main():
-    # stdout carries exactly ONE line (the JSON result): library banners (RCCL prints its version table on
-    # stdout when the communicator is created) and stray prints are routed to stderr at the fd level.
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 8 frames per GPU (the reference's own data-parallel mode: the per-rank batch of the config, "
+                         "rpn_multiclass.config:206); strong: a global batch of 8 frames split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-table", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the geometry ops inline instead of one step ahead")
@@ -291,14 +289,80 @@ def main():
                     help="batches whose geometry is computed in one launch (0 = the largest divisor of --steps up to 16, "
                          "so that the timed steps contain exactly as many geometry launches as they consume)")
     ap.add_argument("--cpu-frames", type=int, default=48)
-    args = ap.parse_args()
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU test hook: the ranks join a gloo group and time a stand-in step (no HIP); exercises the "
+                         "launcher / barrier / max-over-ranks / one-JSON-line plumbing without a GPU")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a CHILD job
+    (python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) and relay its one JSON line.
+    This process has not touched the GPU (no HIP call, no torch.cuda call) and never execs."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in out.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return out.returncode if (out.returncode != 0 or lines) else 1
+
+
+def stub_main(args):
+    """--stub: the measurement plumbing on CPU ranks (gloo): same barrier / max-over-ranks / rank-0 JSON line."""
+    from heterofusionrcnn_amd import dp
+    ctx = dp.init("gloo")
+    per_rank = B if args.scaling == "weak" else max(1, B // ctx.world)
+    torch.manual_seed(0)
+    w = torch.nn.Linear(16, 16)
+    net = dp.wrap_model(w, ctx)
+    x = torch.randn(per_rank, 16)
+    for _ in range(args.warmup):
+        net(x).sum().backward()
+    dp.fence(ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net(x).sum().backward()
+    dp.fence(ctx)
+    dt = dp.max_over_ranks(time.perf_counter() - t0, ctx)
+    if ctx.rank == 0:
+        print(json.dumps({"metric": "stub frames/sec (CPU plumbing test)", "value": round(ctx.world * per_rank * args.steps / dt, 3),
+                          "unit": "frames/s", "n_gpus": ctx.world, "ranks": ctx.world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "stub", "frames_per_gpu": per_rank, "global_batch": per_rank * ctx.world}}))
+    dp.shutdown(ctx)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    # BEFORE anything touches the GPU: without a launcher around us, N > 1 ranks are started as a child job
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    if args.stub:
+        return stub_main(args)
+    # stdout carries exactly ONE line (the JSON result): library banners (RCCL prints its version table on
+    # stdout when the communicator is created) and stray prints are routed to stderr at the fd level.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     from heterofusionrcnn_amd import dp
     ctx = dp.init("nccl")   # RCCL; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher
     world, rank, local_rank = ctx.world, ctx.rank, ctx.local_rank
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started by a launcher with WORLD_SIZE=%d" % (args.gpus, world))
 
     import heterofusionrcnn_amd as hf
     from heterofusionrcnn_amd import modules

@@ -1,4 +1,5 @@
-// grouping.hip -- query_ball_point / group_point (+grad) / fused ball-group / select_top_k for gfx950.
+// grouping.hip -- brute-force query_ball_point (fallback; the main kernel is in ballquery.hip) / group_point (+grad) /
+// group_concat / knn_point / select_top_k for gfx950, and the ball-query entry points.
 //
 // Replaces grouping/tf_grouping_g.cu:3-123 of the reference (launchers :125-141).
 //
@@ -105,435 +106,6 @@ __global__ __launch_bounds__(kQbThreads) void qbp_bruteforce_kernel(int n, int m
             if (center) v = v - p2[(j0 + r) * 3 + d];
             g[e] = v;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Slab ball query (main path).  One launch, grid (S slabs, B clouds), 1024 threads per workgroup.
-//
-// A brute-force scan is B*M*N pair tests (537 M at the headline shape) although a 0.5 m ball holds a
-// handful of points; the reference's early `break` almost never fires.  Here every workgroup
-//   A  histograms the cloud's QUERIES along their widest axis (1024 bins) and cuts that axis into S
-//      quantile slabs -- every workgroup of a cloud derives the same cut from the same data, so the
-//      slabs partition the queries without any inter-workgroup communication;
-//   B  streams the N data points once and keeps only those inside the bounding box of its own
-//      queries grown by the radius (a few hundred to a few thousand points) in LDS;
-//   C  counting-sorts these candidates along the second-widest axis into bins at least one radius
-//      wide, so a query's possible neighbours are ONE contiguous run of three bins;
-//   D  one thread per query tests that run with the reference's exact fp32 expression and keeps the
-//      nsample SMALLEST data indices in a sorted LDS row (= the first nsample hits of the
-//      reference's ascending scan), counting all hits;
-//   E  all threads write idx / pts_cnt / grouped_xyz rows, padded with the first hit.
-// Results are independent of S, of the axis choice and of the candidate order: the set of hits is
-// decided by the same `s < thresh` test and the order by the data index alone.
-// ------------------------------------------------------------------------------------------
-constexpr int kSlabThreads = 1024;
-constexpr int kSlabWaves = kSlabThreads / kWave;
-constexpr int kSlabBins = 1024;       // histogram bins along the slab axis == threads
-constexpr int kSlabZBins = 1024;      // bins along the second axis
-
-struct SlabShared {
-    unsigned qmin[3], qmax[3];   // ordered-uint bbox of ALL queries of the cloud
-    int wsum[kSlabWaves];
-    int b0, b1;                  // first / last histogram bin of this slab (-1: none)
-    int pre0, pre1;              // queries before the slab / up to its end
-    int nq;                      // slot counter of the single-round collection
-};
-
-// per-wave DPP reduction, then ONE lane touches LDS.  (A same-address LDS atomic issued by all 64 lanes
-// is rewritten by hipcc's atomic optimizer into a 64-iteration scalar v_readlane loop: 20 us for the six
-// bbox atomics of this kernel, measured.)
-__device__ __forceinline__ void wave_bbox_merge(const float lo[3], const float hi[3], unsigned *smin, unsigned *smax)
-{
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const unsigned a = wave_min_u32(f2ord(lo[d]));
-        const unsigned b = wave_max_u32(f2ord(hi[d]));
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&smin[d], a);
-            atomicMax(&smax[d], b);
-        }
-    }
-}
-
-// The queries of a cloud are visited four times in phase A (bbox, histogram, ownership, collection).  With
-// QPT > 0 a thread keeps its QPT strided queries in registers after the first visit (m <= QPT * 1024);
-// QPT == 0 re-reads them from global memory (any m).
-template <int QPT> struct QueryRegs { float x[QPT > 0 ? QPT : 1], y[QPT > 0 ? QPT : 1], z[QPT > 0 ? QPT : 1]; };
-
-template <int QPT, typename F>
-__device__ __forceinline__ void for_each_query(int m, const float *__restrict__ p2, const QueryRegs<QPT> &qr, F &&f)
-{
-    const int t = threadIdx.x;
-    if constexpr (QPT > 0) {
-#pragma unroll
-        for (int i = 0; i < QPT; ++i) {
-            const int j = t + i * kSlabThreads;
-            if (j < m) f(i, j, qr.x[i], qr.y[i], qr.z[i]);
-        }
-    } else {
-        int i = 0;
-        for (int j = t; j < m; j += kSlabThreads, ++i) f(i, j, p2[j * 3 + 0], p2[j * 3 + 1], p2[j * 3 + 2]);
-    }
-}
-
-constexpr int kSlabPPT = 8;   // data points prefetched into registers per thread and super-step
-constexpr int kSlabG = 8;     // lanes cooperating on one query in phase D
-constexpr int kSlotBits = 12; // row entries carry the candidate's slot in the LDS buffer when n < 2^(31-12)
-
-template <bool GROUP, int QPT>
-__global__ __launch_bounds__(kSlabThreads) void qbp_slab_kernel(int n, int m, int nslab, float radius, float thresh,
-                                                                int nsample, int qcap, int ccap, int stop,
-                                                                int slot_bits, const float *__restrict__ xyz1,
-                                                                const float *__restrict__ xyz2, int center,
-                                                                int *__restrict__ idx, int *__restrict__ pts_cnt,
-                                                                float *__restrict__ grouped)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // carve dynamic LDS (everything in ONE array; 16-byte aligned pieces)
-    static_assert(sizeof(SlabShared) <= 128, "SlabShared must fit its 128-byte slot");
-    SlabShared &sh = *reinterpret_cast<SlabShared *>(smem_raw);
-    int *hist = reinterpret_cast<int *>(smem_raw + 128);              // kSlabBins (reused: slab id per bin)
-    int *zstart = hist + kSlabBins;                                   // kSlabZBins + 1
-    float4 *qbuf = reinterpret_cast<float4 *>(zstart + kSlabZBins + 4);  // qcap   (x,y,z,j)
-    float4 *cand = qbuf + qcap;                                       // ccap   (x,y,z,k) in arrival order
-    float4 *sorted = cand + ccap;                                     // ccap   the same, ordered by second-axis bin
-    int *rows = reinterpret_cast<int *>(sorted + ccap);               // qcap * rs  K smallest indices, ascending
-    int *hits = rows + qcap * (nsample | 1);                          // qcap  total hits per query
-    int *stage = hits + qcap;                                         // kSlabThreads: phase-D hand-off inside a wave
-    const int rs = nsample | 1;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    // grid = (clouds, slabs): linear workgroup id = cloud + B*slab, and workgroups are dealt round-robin over
-    // the 8 XCDs, so with B = 8 all slabs of one cloud share ONE XCD's L2 (the cloud is fetched once per XCD
-    // instead of once per XCD per cloud).  Placement is a speed matter only.
-    const int slab = blockIdx.y, bb = blockIdx.x;
-    const float *p1 = xyz1 + static_cast<size_t>(bb) * n * 3;
-    const float *p2 = xyz2 + static_cast<size_t>(bb) * m * 3;
-
-    if (stop == -1) return;
-    // ---------------- A1: bbox of all queries ----------------
-    if (t < 3) { sh.qmin[t] = 0xffffffffu; sh.qmax[t] = 0u; }
-    if (t == 3) { sh.b0 = -1; sh.b1 = -1; sh.pre0 = 0; sh.pre1 = 0; }
-    hist[t] = 0;
-    __syncthreads();
-    QueryRegs<QPT> qr;
-    {
-        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        if constexpr (QPT > 0) {
-#pragma unroll
-            for (int i = 0; i < QPT; ++i) {
-                const int j = t + i * kSlabThreads;
-                const int jj = j < m ? j : 0;
-                qr.x[i] = p2[jj * 3 + 0]; qr.y[i] = p2[jj * 3 + 1]; qr.z[i] = p2[jj * 3 + 2];
-            }
-        }
-        for_each_query<QPT>(m, p2, qr, [&](int, int, float qx, float qy, float qz) {
-            lo[0] = fminf(lo[0], qx); hi[0] = fmaxf(hi[0], qx);
-            lo[1] = fminf(lo[1], qy); hi[1] = fmaxf(hi[1], qy);
-            lo[2] = fminf(lo[2], qz); hi[2] = fmaxf(hi[2], qz);
-        });
-        wave_bbox_merge(lo, hi, sh.qmin, sh.qmax);
-    }
-    __syncthreads();
-    if (stop == -2) return;
-    float qlo[3], qhi[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { qlo[d] = ord2f(sh.qmin[d]); qhi[d] = ord2f(sh.qmax[d]); }
-    int ax = 0;  // slab axis = widest query extent
-    if (qhi[1] - qlo[1] > qhi[ax] - qlo[ax]) ax = 1;
-    if (qhi[2] - qlo[2] > qhi[ax] - qlo[ax]) ax = 2;
-    const float aext = qhi[ax] - qlo[ax];
-    const float ascale = aext > 0.0f ? static_cast<float>(kSlabBins) / aext : 0.0f;
-    const float alo = qlo[ax];
-    auto abin = [&](float v) -> int {
-        int bq = static_cast<int>((v - alo) * ascale);
-        return bq < 0 ? 0 : (bq > kSlabBins - 1 ? kSlabBins - 1 : bq);
-    };
-
-    // ---------------- A2/A3: histogram -> quantile slab of every bin ----------------
-    for_each_query<QPT>(m, p2, qr, [&](int, int, float qx, float qy, float qz) {
-        atomicAdd(&hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))], 1);
-    });
-    __syncthreads();
-    if (stop == -3) return;
-    const int hcount = hist[t];
-    const int before = block_exclusive_scan(hcount, sh.wsum, nullptr);
-    // before < m and nslab <= 256, m * nslab < 2^31 is checked on the host: 32-bit division
-    int myslab = static_cast<int>((static_cast<unsigned>(before) * static_cast<unsigned>(nslab)) / static_cast<unsigned>(m));
-    if (myslab > nslab - 1) myslab = nslab - 1;
-    __syncthreads();
-    hist[t] = myslab;  // bin -> slab (monotone in the bin index)
-    __syncthreads();
-    // my slab is one contiguous run of bins [b0, b1]; its first / last bin publish the run and the number of
-    // queries before / up to it (the histogram prefix), so the slab's query count needs no second scan
-    if (myslab == slab) {
-        if (t == 0 || hist[t - 1] != slab) { sh.b0 = t; sh.pre0 = before; }
-        if (t == kSlabBins - 1 || hist[t + 1] != slab) { sh.b1 = t; sh.pre1 = before + hcount; }
-    }
-    if (t == 0) { sh.nq = 0; }
-    __syncthreads();
-    if (sh.b1 < 0) return;  // no bin maps to this slab (fewer distinct bins than slabs)
-    const int nq_total = sh.pre1 - sh.pre0;
-    if (nq_total == 0) return;
-    if (stop == 1) return;  // diagnostic phase timing only (HF_QBP_STOP), never set in production
-
-    // pad for every box / bin growth: > radius plus fp32 rounding of the box corners
-    float amax = 0.0f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) amax = fmaxf(amax, fmaxf(fabsf(qlo[d]), fabsf(qhi[d])));
-    const float rp = radius * 1.001f + 1e-6f * amax;
-
-    // candidate box of the slab: along the slab axis the bin run grown by half a bin on each side (covers the
-    // fp32 rounding of the bin computation), on the other axes the extent of all queries; plus the radius pad
-    float blo[3], bhi[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { blo[d] = qlo[d] - rp; bhi[d] = qhi[d] + rp; }
-    if (ascale > 0.0f) {
-        const float binw = 1.0f / ascale;
-        const float slo = alo + (static_cast<float>(sh.b0) - 0.5f) * binw - rp;
-        const float shi = alo + (static_cast<float>(sh.b1) + 1.5f) * binw + rp;
-        if (ax == 0) { blo[0] = fmaxf(blo[0], slo); bhi[0] = fminf(bhi[0], shi); }
-        else if (ax == 1) { blo[1] = fmaxf(blo[1], slo); bhi[1] = fminf(bhi[1], shi); }
-        else { blo[2] = fmaxf(blo[2], slo); bhi[2] = fminf(bhi[2], shi); }
-    }
-    // second axis: the wider of the other two
-    const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
-    const int zx = (bhi[a1] - blo[a1]) >= (bhi[a2] - blo[a2]) ? a1 : a2;
-    const float zlo = blo[zx];
-    const float zext = bhi[zx] - blo[zx];
-    const float zsize = fmaxf(rp * 1.01f, zext / static_cast<float>(kSlabZBins - 2));
-    const float zscale = 1.0f / zsize;
-    auto zbin = [&](float v) -> int {
-        int bq = static_cast<int>((v - zlo) * zscale);
-        return bq < 0 ? 0 : (bq > kSlabZBins - 1 ? kSlabZBins - 1 : bq);
-    };
-
-    // ---------------- A4: collect my queries ----------------
-    // common case (they all fit one round): any unique slot will do -> a wave-aggregated LDS counter.
-    // otherwise: fixed ranks from a block scan so that the rounds partition the queries consistently.
-    const bool single = nq_total <= qcap;
-    unsigned ownmask = 0;
-    int owncnt = 0, rank0 = 0;
-    if (!single) {
-        for_each_query<QPT>(m, p2, qr, [&](int i, int, float qx, float qy, float qz) {
-            const bool own = hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))] == slab;
-            if (own) { ++owncnt; if (i < 32) ownmask |= 1u << i; }
-        });
-        rank0 = block_exclusive_scan(owncnt, sh.wsum, nullptr);
-    }
-
-    for (int round0 = 0; round0 < nq_total; round0 += qcap) {
-        if (single) {
-            for_each_query<QPT>(m, p2, qr, [&](int, int j, float qx, float qy, float qz) {
-                if (hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))] == slab)
-                    qbuf[atomicAdd(&sh.nq, 1)] = make_float4(qx, qy, qz, __int_as_float(j));
-            });
-        } else if (owncnt > 0) {
-            int rank = rank0;
-            for_each_query<QPT>(m, p2, qr, [&](int i, int j, float qx, float qy, float qz) {
-                bool own;
-                if (i < 32) own = (ownmask >> i) & 1u;
-                else own = hist[abin(ax == 0 ? qx : (ax == 1 ? qy : qz))] == slab;
-                if (!own) return;
-                if (rank >= round0 && rank < round0 + qcap) qbuf[rank - round0] = make_float4(qx, qy, qz, __int_as_float(j));
-                ++rank;
-            });
-        }
-        __syncthreads();
-        if (stop == 2) return;
-        const int nq = min(qcap, nq_total - round0);
-        for (int q = t; q < nq; q += kSlabThreads) hits[q] = 0;
-
-        // ---- C + D on the current candidate buffer (nc entries); called by all threads together ----
-        auto flush = [&](int nc) {
-            // C: counting sort of the candidates by second-axis bin
-            zstart[t] = 0;
-            __syncthreads();
-            for (int c = t; c < nc; c += kSlabThreads) {
-                const float4 v = cand[c];
-                atomicAdd(&zstart[zbin(zx == 0 ? v.x : (zx == 1 ? v.y : v.z))], 1);
-            }
-            __syncthreads();
-            const int zc = zstart[t];
-            const int zoff = block_exclusive_scan(zc, sh.wsum, nullptr);
-            zstart[t] = zoff;  // start of bin t
-            __syncthreads();
-            for (int c = t; c < nc; c += kSlabThreads) {
-                const float4 v = cand[c];
-                sorted[atomicAdd(&zstart[zbin(zx == 0 ? v.x : (zx == 1 ? v.y : v.z))], 1)] = v;
-            }
-            __syncthreads();
-            // zstart[b] now holds the END of bin b == start of bin b+1; start of bin 0 is 0
-            // D: kSlabG lanes per query; the group's lane 0 owns the sorted row
-            const int sub = t & (kSlabG - 1);
-            const int gbase = lane & ~(kSlabG - 1);
-            for (int q0 = 0; q0 < nq; q0 += kSlabThreads / kSlabG) {
-                const int q = q0 + (t / kSlabG);
-                const bool live = q < nq;
-                float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
-                int i0 = 0, i1 = 0;
-                if (live) {
-                    qq = qbuf[q];
-                    const int bq = zbin(zx == 0 ? qq.x : (zx == 1 ? qq.y : qq.z));
-                    i0 = bq >= 2 ? zstart[bq - 2] : 0;                                          // start of bin bq-1
-                    i1 = zstart[bq + 1 > kSlabZBins - 1 ? kSlabZBins - 1 : bq + 1];           // end of bin bq+1
-                }
-                const int iters = static_cast<int>(wave_max_u32(static_cast<unsigned>((i1 - i0 + kSlabG - 1) / kSlabG)));
-                int *row = rows + q * rs;
-                int total = 0, len = 0;
-                if (live && sub == 0) { total = hits[q]; len = total < nsample ? total : nsample; }
-                for (int it = 0; it < iters; ++it) {
-                    const int i = i0 + it * kSlabG + sub;
-                    bool hit = false;
-                    int k = 0;  // row entry: (data index << kSlotBits) | slot in `sorted` -- ordered by data index
-                    if (i < i1) {
-                        const float4 c = sorted[i];
-                        const float dx = qq.x - c.x, dy = qq.y - c.y, dz = qq.z - c.z;
-                        const float s2 = dx * dx + dy * dy + dz * dz;
-                        hit = s2 < thresh;
-                        k = (__float_as_int(c.w) << slot_bits) | (slot_bits ? i : 0);
-                    }
-                    const unsigned long long bal = __ballot(hit);
-                    if (bal == 0ull) continue;  // wave-uniform
-                    if (hit) stage[t] = k;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (sub == 0) {
-                        unsigned bits = static_cast<unsigned>(bal >> gbase) & ((1u << kSlabG) - 1u);
-                        while (bits) {
-                            const int src = __builtin_ctz(bits);
-                            bits &= bits - 1u;
-                            const int kk = stage[t + src];
-                            ++total;
-                            if (len < nsample || kk < row[len - 1]) {
-                                int pos = len < nsample ? len++ : len - 1;
-                                while (pos > 0 && row[pos - 1] > kk) { row[pos] = row[pos - 1]; --pos; }
-                                row[pos] = kk;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (live && sub == 0) hits[q] = total;
-            }
-            __syncthreads();
-        };
-
-        // ---------------- B: stream the data points through registers ----------------
-        int nflush = 0;  // flushes of this round: with exactly one, `sorted` still holds every row's candidates in E
-        int nc = 0;  // candidates in the LDS buffer: every thread tracks the same value
-        for (int base = 0; base < n; base += kSlabPPT * kSlabThreads) {
-            float px[kSlabPPT], py[kSlabPPT], pz[kSlabPPT];
-#pragma unroll
-            for (int u = 0; u < kSlabPPT; ++u) {
-                const int k = base + u * kSlabThreads + t;
-                const int kk = k < n ? k : 0;
-                px[u] = p1[kk * 3 + 0]; py[u] = p1[kk * 3 + 1]; pz[u] = p1[kk * 3 + 2];
-            }
-            unsigned inmask = 0;
-#pragma unroll
-            for (int u = 0; u < kSlabPPT; ++u) {
-                const int k = base + u * kSlabThreads + t;
-                const bool in = k < n && px[u] >= blo[0] && px[u] <= bhi[0] && py[u] >= blo[1] && py[u] <= bhi[1] &&
-                                pz[u] >= blo[2] && pz[u] <= bhi[2];
-                inmask |= (in ? 1u : 0u) << u;
-            }
-            int tot;
-            const int off = block_exclusive_scan(__builtin_popcount(inmask), sh.wsum, &tot);
-            if (nc + tot <= ccap) {
-                // common case: everything fits, positions from the scan (no atomics)
-                int pos = nc + off;
-#pragma unroll
-                for (int u = 0; u < kSlabPPT; ++u)
-                    if ((inmask >> u) & 1u)
-                        cand[pos++] = make_float4(px[u], py[u], pz[u], __int_as_float(base + u * kSlabThreads + t));
-                nc += tot;
-            } else {
-                // dense data: push one register slot at a time, flushing whenever the next slot might not fit
-#pragma unroll 1
-                for (int u = 0; u < kSlabPPT; ++u) {
-                    if (nc + kSlabThreads > ccap) {
-                        __syncthreads();
-                        flush(nc);
-                        ++nflush;
-                        nc = 0;
-                    }
-                    const int bit = (inmask >> u) & 1u;
-                    int tu;
-                    const int ou = block_exclusive_scan(bit, sh.wsum, &tu);
-                    float x = 0.f, y = 0.f, z = 0.f;
-#pragma unroll
-                    for (int v = 0; v < kSlabPPT; ++v)
-                        if (v == u) { x = px[v]; y = py[v]; z = pz[v]; }
-                    if (bit) cand[nc + ou] = make_float4(x, y, z, __int_as_float(base + u * kSlabThreads + t));
-                    nc += tu;
-                }
-            }
-        }
-        __syncthreads();
-        if (stop == 3) return;
-        if (nc > 0) { flush(nc); ++nflush; }
-        if (stop == 5) return;
-        const bool from_lds = slot_bits != 0 && nflush == 1;  // uniform
-
-        // ---------------- E: write this round's rows ----------------
-        for (int q = t; q < nq; q += kSlabThreads) {
-            if (pts_cnt) {
-                const int j = __float_as_int(qbuf[q].w);
-                pts_cnt[static_cast<size_t>(bb) * m + j] = min(hits[q], nsample);
-            }
-        }
-        const int total_e = nq * nsample;
-        if (idx) {
-            for (int e = t; e < total_e; e += kSlabThreads) {
-                const int q = e / nsample, c = e - q * nsample;
-                const int j = __float_as_int(qbuf[q].w);
-                const int h = min(hits[q], nsample);
-                idx[(static_cast<size_t>(bb) * m + j) * nsample + c] = h == 0 ? 0 : (rows[q * rs + (c < h ? c : 0)] >> slot_bits);
-            }
-        }
-        if (GROUP) {
-            // one (query, slot) pair per lane: a 12-byte gather from the cloud, a 12-byte store into the
-            // row; consecutive lanes write consecutive triples.  U pairs in flight per thread.
-            constexpr int U = 4;
-            typedef float f3 __attribute__((ext_vector_type(3)));
-            for (int e0 = t; e0 < total_e; e0 += kSlabThreads * U) {
-                f3 v[U];
-                f3 cq[U];
-                size_t dst[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = e0 + u * kSlabThreads;
-                    const int ee = e < total_e ? e : 0;
-                    const int q = ee / nsample, c = ee - q * nsample;
-                    const float4 qq = qbuf[q];
-                    const int j = __float_as_int(qq.w);
-                    const int h = min(hits[q], nsample);
-                    const int packed = h == 0 ? 0 : rows[q * rs + (c < h ? c : 0)];
-                    if (from_lds && h != 0) {
-                        const float4 cc = sorted[packed & ((1 << kSlotBits) - 1)];  // same values as the cloud's
-                        v[u] = f3{ cc.x, cc.y, cc.z };
-                    } else {
-                        const float *src = p1 + static_cast<size_t>(packed >> slot_bits) * 3;
-                        v[u] = f3{ src[0], src[1], src[2] };
-                    }
-                    cq[u] = f3{ qq.x, qq.y, qq.z };
-                    dst[u] = ((static_cast<size_t>(bb) * m + j) * nsample + c) * 3;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (e0 + u * kSlabThreads < total_e) {
-                        f3 o = v[u];
-                        if (center) o = o - cq[u];
-                        float *g = grouped + dst[u];
-                        g[0] = o.x; g[1] = o.y; g[2] = o.z;
-                    }
-                }
-            }
-        }
-        __syncthreads();  // qbuf / rows / hits reused by the next round
     }
 }
 
@@ -750,12 +322,6 @@ static int grid_for(long long work_items, int block)
     return static_cast<int>(g);
 }
 
-static size_t slab_lds_bytes(int nsample, int qcap, int ccap)
-{
-    return 128 + sizeof(int) * (kSlabBins + kSlabZBins + 4) + sizeof(float4) * (static_cast<size_t>(qcap) + 2 * ccap) +
-           sizeof(int) * (static_cast<size_t>(qcap) * (nsample | 1) + qcap + kSlabThreads);
-}
-
 static int launch_ball_query_bruteforce(int b, int n, int m, float thresh, int nsample, const float *xyz1,
                                         const float *xyz2, int center, int *idx, int *pts_cnt, float *grouped,
                                         hipStream_t st)
@@ -780,12 +346,6 @@ static int launch_ball_query_bruteforce(int b, int n, int m, float thresh, int n
 }
 
 // HF_BALL_QUERY=bruteforce forces the fallback kernel (used by the tests to cover both paths)
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e && e[0] ? atoi(e) : dflt;
-}
-
 static bool force_bruteforce()
 {
     const char *e = getenv("HF_BALL_QUERY");
@@ -796,46 +356,13 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
                              int center, int *idx, int *pts_cnt, float *grouped, hipStream_t st)
 {
     const float thresh = ball_threshold(radius);
-    // slab kernel geometry: LDS rows hold nsample ints per query
-    int qcap, ccap;
-    if (nsample <= 32) { qcap = 256; ccap = 3072; }
-    else if (nsample <= 64) { qcap = 256; ccap = 2048; }
-    else if (nsample <= 128) { qcap = 128; ccap = 2048; }
-    else { qcap = 0; ccap = 0; }
-    const bool finite_r = radius < 3.0e18f;  // padded boxes stay finite
-    if (qcap == 0 || !finite_r || force_bruteforce() || static_cast<long long>(m) * kNumCU > 0x7fffffffLL)
-        return launch_ball_query_bruteforce(b, n, m, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
-    // one workgroup per CU across the batch, at least ~64 queries per slab
-    int nslab = kNumCU / b;
-    if (nslab > m / 64) nslab = m / 64;
-    if (nslab < 1) nslab = 1;
-    nslab = env_int("HF_QBP_SLABS", nslab);      // diagnostics only
-    qcap = env_int("HF_QBP_QCAP", qcap);         // diagnostics only (LDS geometry)
-    ccap = env_int("HF_QBP_CCAP", ccap);
-    const int stop = env_int("HF_QBP_STOP", 0);  // diagnostics only: early exit after phase N (outputs invalid)
-    const size_t lds = slab_lds_bytes(nsample, qcap, ccap);
-    dim3 grid(b, nslab);
-    // (data index, LDS slot) packed in one int: needs n < 2^19 and every slot < 2^12
-    const int slot_bits = (n < (1 << (31 - kSlotBits)) && ccap <= (1 << kSlotBits)) ? kSlotBits : 0;
-#define HF_SLAB_LAUNCH(G, Q)                                                                                          \
-    do {                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_slab_kernel<G, Q>),                            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
-        hipLaunchKernelGGL((qbp_slab_kernel<G, Q>), grid, dim3(kSlabThreads), lds, st, n, m, nslab, radius, thresh,    \
-                           nsample, qcap, ccap, stop, slot_bits, xyz1, xyz2, center, idx, pts_cnt, grouped);         \
-    } while (0)
-    // queries held in registers when they fit (4 per thread up to m = 4096, 8 up to 8192)
-    if (grouped) {
-        if (m <= 4 * kSlabThreads) HF_SLAB_LAUNCH(true, 4);
-        else if (m <= 8 * kSlabThreads) HF_SLAB_LAUNCH(true, 8);
-        else HF_SLAB_LAUNCH(true, 0);
-    } else {
-        if (m <= 4 * kSlabThreads) HF_SLAB_LAUNCH(false, 4);
-        else if (m <= 8 * kSlabThreads) HF_SLAB_LAUNCH(false, 8);
-        else HF_SLAB_LAUNCH(false, 0);
+    // main path: the cell kernel (ballquery.hip); shapes outside its range (nsample > 128, n > 2^19 points per cloud,
+    // infinite radius) take the brute-force kernel
+    if (!force_bruteforce()) {
+        const int rc = launch_ball_query_cell(b, n, m, radius, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
+        if (rc != HF_EINVAL) return rc;
     }
-#undef HF_SLAB_LAUNCH
-    return launch_status();
+    return launch_ball_query_bruteforce(b, n, m, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
 }
 
 // ------------------------------------------------------------------------------------------

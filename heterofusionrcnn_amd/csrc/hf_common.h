@@ -36,6 +36,10 @@ size_t knn_grid_workspace(int b, int n);
 int launch_knn_grid(int b, int n, int m, int k, const float *data, const float *queries, float *val, int *idx,
                     void *workspace, hipStream_t st);
 
+// ballquery.hip: the cell ball-query kernel; HF_EINVAL = shape outside its range (caller falls back)
+int launch_ball_query_cell(int b, int n, int m, float radius, float thresh, int nsample, const float *xyz1,
+                           const float *xyz2, int center, int *idx, int *pts_cnt, float *grouped, hipStream_t st);
+
 // status of the launch that was just enqueued (no synchronisation)
 inline int launch_status() { return hip_status(hipGetLastError()); }
 
@@ -124,6 +128,20 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total
     __syncthreads();  // wsum reusable
     if (total) *total = tot;
     return base + inc - v;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside each 16-lane row (row_shr, lanes shifted in
+// from outside the row read 0), then row_bcast:15 / row_bcast:31 carry the row totals across rows.  6 DPP adds,
+// no LDS crossbar (a __shfl_up chain is 6 ds_bpermute round trips).
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
 }
 
 __device__ __forceinline__ int lane_id() { return static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }

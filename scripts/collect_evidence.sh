@@ -17,4 +17,4 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/scripts/roofline_kernel.py > $OUT/pmc_fetch.log 2>&1 && \
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/scripts/roofline_kernel.py > $OUT/pmc_write.log 2>&1; echo "pmc exit $?"
 cd $GRAFT_REPO_ROOT
-python scripts/parse_pmc.py $OUT/pmc_fetch qbp_slab; python scripts/parse_pmc.py $OUT/pmc_write qbp_slab
+python scripts/parse_pmc.py $OUT/pmc_fetch qbp_cell; python scripts/parse_pmc.py $OUT/pmc_write qbp_cell

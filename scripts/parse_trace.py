@@ -14,7 +14,8 @@ def flush():
 for r in rows:
     if pat and pat not in r["Kernel_Name"]:
         continue
-    if group and r["Kernel_Name"] != group[0]["Kernel_Name"]:
+    # a new group on a kernel-name change, or after an idle gap (a host sync between two bursts of one kernel)
+    if group and (r["Kernel_Name"] != group[0]["Kernel_Name"] or int(r["Start_Timestamp"]) - int(group[-1]["End_Timestamp"]) > 100000):
         flush(); group = []
     group.append(r)
 flush()

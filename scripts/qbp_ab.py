@@ -1,0 +1,74 @@
+"""A/B of the ball-query kernel's variants at the headline shape (B=8, N=16384, M=4096, K=32, r=0.5) and at the in-step
+batched shape (80 clouds): brute force (the fallback), the 512-thread form, and the three store flavours of the cell kernel.
+Bursts of direct C-ABI launches (outputs preallocated) bracketed by two HIP events = kernel + launch gap; the bare
+kernel durations come from rocprofv3 --kernel-trace of the same script."""
+import os, sys, json, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import heterofusionrcnn_amd as hf
+from heterofusionrcnn_amd import _lib
+from bench import kitti_uniform
+import oracle
+
+L = _lib.lib()
+
+
+def burst(args, fn, launches=200):
+    for _ in range(10):
+        assert fn(*args) == 0
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        fn(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    time.sleep(0.002)   # an idle gap: scripts/parse_trace.py splits the kernel trace into bursts there
+    return round(1e3 * e0.elapsed_time(e1) / launches, 2)
+
+
+res = {}
+rng = np.random.default_rng(0)
+K, R = 32, 0.5
+for B in (8, 80):
+    xyz = torch.from_numpy(kitti_uniform(rng, B, 16384)).cuda()
+    m = 4096
+    new_xyz = hf.gather_point(xyz, hf.farthest_point_sample(m, xyz))
+    idx = torch.empty((B, m, K), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((B, m), dtype=torch.int32, device="cuda")
+    grouped = torch.empty((B, m, K, 3), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    a_fused = (B, 16384, m, R, K, xyz.data_ptr(), new_xyz.data_ptr(), 1, idx.data_ptr(), cnt.data_ptr(), grouped.data_ptr(), st)
+    a_qbp = (B, 16384, m, R, K, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), cnt.data_ptr(), st)
+    ref = None
+    for name, env in (("cell512_nt", {"HF_QBP_NT": "512"}),
+                      ("cell_plain", {"HF_QBP_STORE": "0"}), ("cell_nt", {"HF_QBP_STORE": "1"}),
+                      ("cell_wt", {"HF_QBP_STORE": "2"})):
+        for k in ("HF_BALL_QUERY", "HF_QBP_STORE", "HF_QBP_NT"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        idx.fill_(-7); cnt.fill_(-7); grouped.fill_(-7.0)
+        assert L.hf_query_ball_group_xyz(*a_fused) == 0
+        torch.cuda.synchronize()
+        out = (idx.clone(), cnt.clone(), grouped.clone())
+        if ref is None:
+            ref = out
+        else:
+            for a, b in zip(ref, out):
+                assert torch.equal(a, b), name
+        res["B%d_%s_fused_us" % (B, name)] = burst(a_fused, L.hf_query_ball_group_xyz)
+        res["B%d_%s_qbp_only_us" % (B, name)] = burst(a_qbp, L.hf_query_ball_point)
+    if B == 8:
+        o_idx, o_cnt = oracle.query_ball_point(R, K, xyz[:1].cpu().numpy(), new_xyz[:1].cpu().numpy())
+        assert np.array_equal(ref[0][:1].cpu().numpy(), o_idx) and np.array_equal(ref[1][:1].cpu().numpy(), o_cnt)
+        for k in ("HF_BALL_QUERY", "HF_QBP_STORE", "HF_QBP_NT"):
+            os.environ.pop(k, None)
+        if os.environ.get("PHASES"):
+            os.environ["HF_QBP_STORE"] = os.environ.get("PHASE_STORE", "0")
+            for stop in (-1, -2, 1, 2, 4, 0):
+                os.environ["HF_QBP_STOP"] = str(stop)
+                res["cell_stop%d_us" % stop] = burst(a_fused, L.hf_query_ball_group_xyz)
+            os.environ.pop("HF_QBP_STOP")
+for k in ("HF_BALL_QUERY", "HF_QBP_STORE", "HF_QBP_NT"):
+    os.environ.pop(k, None)
+print(json.dumps(res, indent=1))

@@ -178,9 +178,10 @@ def test_oracle_ball_query(hf, oracle_mod, b, n, m, r, ns):
 
 
 def test_ball_query_both_kernels_and_stress_paths(hf, oracle_mod):
-    """slab kernel: several rounds per slab (clustered queries), candidate-buffer flushes (dense data),
-    hits >> nsample, every LDS geometry (nsample 32/64/128) and the brute-force fallback (nsample > 128 or
-    HF_BALL_QUERY=bruteforce) -- all must give the oracle's rows"""
+    """cell kernel (ballquery.hip): clustered queries, dense data (candidate buffer overflow -> chunked walk with early
+    stop, more than two hits per list -> serial hand-off), hits >> nsample, several register segments (n > 16384), every
+    LDS geometry (nsample 32/64/128), the exhaustive mode (coordinates ~1e6 radii from the origin) and the brute-force
+    kernel (nsample > 128, n > 2^19, HF_BALL_QUERY=bruteforce) -- all must give the oracle's rows"""
     rng = np.random.default_rng(77)
     cases = []
     # clustered queries: ~2900 of 3000 queries sit in a 1 cm cube -> one slab owns them all (rounds)
@@ -203,6 +204,16 @@ def test_ball_query_both_kernels_and_stress_paths(hf, oracle_mod):
     cases.append((x1, q, 0.05, 16))
     # huge radius: every point is a hit for every query
     cases.append((kitti_uniform(rng, 2, 700), kitti_uniform(rng, 2, 130), 500.0, 32))
+    # coordinates a million radii away from the origin: the padded box of a query may span three cells -> exhaustive mode
+    x1 = (kitti_uniform(rng, 1, 3000) + np.float32(1.0e6)).astype(np.float32)
+    cases.append((x1, x1[:, ::7].copy(), 0.5, 16))
+    # tiny radius against the coordinates (same switch), hits are the duplicates only
+    x1 = kitti_uniform(rng, 1, 2500)
+    x1[0, 100:110] = x1[0, 5]
+    cases.append((x1, x1[:, :300].copy(), 1e-5, 8))
+    # more than 2^19 points per cloud: outside the cell kernel's index packing -> brute force
+    x1 = kitti_uniform(rng, 1, (1 << 19) + 5)
+    cases.append((x1, x1[:, -12:].copy(), 0.3, 16))
     for mode in ("", "bruteforce"):
         os.environ["HF_BALL_QUERY"] = mode
         try:
