@@ -126,8 +126,9 @@ __device__ __forceinline__ void bn_reduce_channel(const float *__restrict__ part
     q = red[1][0];
 }
 
-// batch statistics, running statistics (torch / TF-EMA semantics: running = (1-m)*running + m*batch,
-// unbiased variance for the running estimate)
+// batch statistics, running statistics: running = (1-m)*running + m*batch with the BIASED batch variance -- what
+// tf.contrib.layers.batch_norm(fused=False) accumulates from tf.nn.moments (hf/core/feature_extractors/tf_util.py:571-581)
+// and tf.layers.batch_normalization does too (torch would use the Bessel-corrected variance here)
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, int c, int nblk,
                                                                 const float *__restrict__ partial, float eps,
                                                                 float momentum, float *__restrict__ running_mean,
@@ -145,10 +146,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, 
     save_mean[ch] = static_cast<float>(mean);
     save_invstd[ch] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
     if (running_mean) running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * static_cast<float>(mean);
-    if (running_var) {
-        const double unbiased = rows > 1 ? var * static_cast<double>(rows) / static_cast<double>(rows - 1) : var;
-        running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * static_cast<float>(unbiased);
-    }
+    if (running_var) running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * static_cast<float>(var);
 }
 
 // y = relu?(gamma*invstd*(x-mean) + beta)

@@ -1,0 +1,396 @@
+"""RPN train step on the HIP ops (BASELINE config 4): point backbone -> foreground segmentation head ->
+bin-based box head -> targets -> focal + softmax + smooth-L1 losses, as hf/core/models/rpn_model.py builds it.
+
+  backbone            hf/core/feature_extractors/pointnet.py:22-153 (SA / SA-MSG down, FP up, conv1d+BN+ReLU fc layers)
+  seg head            rpn_model.py:455-476   dense(K+1), no BN, no activation; softmax
+  fusion              rpn_model.py:515-548   'mean' / 'concat' with the image features under the projected points
+  box head            rpn_model.py:552-581   dense(C)+ELU+BN, dropout, ... ; dense((2 NBX + 2 NBZ + 2 NBT + 4) K) + BN
+  train mode          rpn_model.py:588-590   no decoding, no NMS
+  targets             rpn_model.py:733-796   tf_encode around the point, per-class gathers, one-hot bins
+  losses              rpn_model.py:1040-1128 + hf/core/losses.py:131-226
+  per-point labels    hf/datasets/kitti/kitti_dataset.py:416-440 (point in box -> class + that box)
+
+The network bodies are torch (the GEMMs go to hipBLASLt / the fused MFMA nodes of mlp.py); every sampling / grouping /
+interpolation / encoding step is a HIP op of this package.  TensorFlow cannot be imported here, so the layer semantics
+(`pf.dense` = linear -> ELU -> BatchNorm(momentum 0.99, eps 1e-3), pointfly.py:371-497) are restated from the text:
+parity unpinned against reference outputs; the loss is pinned by a literal op-by-op restatement in tests/test_rpn.py.
+
+The image branch (VGG pyramid, hf/core/feature_extractors/img_vgg_pyramid.py) is outside the path: the
+model takes the image FEATURE MAP as an input and does the reference's projection + gather + fusion on it.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import box_codec
+from .fusion import fuse_point_image_features, project_gather
+from .modules import PointnetFPModule, PointnetSAModule, SharedMLPLayer
+from .grouping import group_concat, group_point, query_ball_group
+from .sampling import farthest_point_sample, gather_point
+from .mlp import BatchNormReLU, shared_mlp
+
+
+# ------------------------------------------------------------------------------------------------ configuration
+@dataclass
+class SAScale:
+    radius: float
+    nsample: int
+    mlp: Tuple[int, ...]
+
+
+@dataclass
+class SALevel:
+    npoint: int
+    scales: Tuple[SAScale, ...]          # one scale = pointnet_sa_module, several = pointnet_sa_module_msg
+
+
+@dataclass
+class RpnConfig:
+    """The values of one reference config file that shape the RPN train step."""
+    name: str
+    num_classes: int = 1
+    pc_sample_pts: int = 16384
+    in_channel: int = 1                                                    # rpn_use_intensity_feature
+    sa: Tuple[SALevel, ...] = ()
+    fp: Tuple[Tuple[int, ...], ...] = ()                                   # deepest first, pointnet.py:108-128
+    backbone_fc: Tuple[Tuple[int, float], ...] = ((256, 0.5), (256, 0.5))  # (C, dropout keep_prob), pointnet.py:131-151
+    rpn_fc: Tuple[Tuple[int, float], ...] = ((512, 0.5), (512, 0.5))       # (C, dropout rate), rpn_model.py:556-568
+    xz_search_range: Tuple[float, ...] = (3.0,)                            # Ss, one per class
+    xz_bin_len: Tuple[float, ...] = (0.5,)                                 # DELTAs
+    theta_search_range: float = 1.0                                        # fraction of pi
+    theta_bin_num: int = 12
+    cluster_sizes: Tuple[Tuple[float, float, float], ...] = ((3.9, 1.6, 1.5),)   # mean (l, w, h) per class
+    fusion: str = "none"                                                   # 'mean' | 'concat' | 'none' (no image branch)
+    img_channels: int = 0
+    seg_loss_weight: float = 100.0
+    cls_loss_weight: float = 1.0
+    reg_loss_weight: float = 1.0
+
+    @property
+    def num_bin_xz(self):
+        return int(2 * self.xz_search_range[0] / self.xz_bin_len[0])       # rpn_model.py:115-116
+
+    @property
+    def r_theta(self):
+        return self.theta_search_range * math.pi                           # rpn_model.py:118
+
+    @property
+    def delta_theta(self):
+        return 2 * self.r_theta / self.theta_bin_num                       # rpn_model.py:119
+
+    @property
+    def head_width(self):
+        return 2 * self.num_bin_xz + 2 * self.num_bin_xz + 2 * self.theta_bin_num + 4
+
+
+def rpn_cars_pointnet_paper() -> RpnConfig:
+    """hf/configs/rpn_cars_pointnet_paper.config:61-152 (MSG set abstraction, 4 FP modules, cars only; its 'mean' fusion
+    needs the image branch: here fusion='none' unless the caller supplies a feature map)."""
+    s = SAScale
+    return RpnConfig(
+        name="rpn_cars_pointnet_paper",
+        sa=(SALevel(4096, (s(0.1, 16, (16, 16, 32)), s(0.5, 32, (32, 32, 64)))),
+            SALevel(1024, (s(0.5, 16, (64, 64, 128)), s(1.0, 32, (64, 96, 128)))),
+            SALevel(512, (s(1.0, 16, (128, 196, 256)), s(2.0, 32, (128, 196, 256)))),
+            SALevel(64, (s(2.0, 16, (256, 256, 512)), s(4.0, 32, (256, 384, 512))))),
+        # the config lists each FP mlp with its INPUT width first (1536 = 1024 + 512, ...); only the outputs are layers
+        fp=((512, 512), (512, 512), (256, 256), (128, 128)))
+
+
+def rpn_stack_config2() -> RpnConfig:
+    """The synthetic single-scale SA+FP stack of BASELINE.json configs[1] with the RPN heads on top."""
+    s = SAScale
+    return RpnConfig(
+        name="sa_fp_stack_config2",
+        sa=(SALevel(4096, (s(0.5, 32, (32, 32, 64)),)), SALevel(1024, (s(1.0, 32, (64, 96, 128)),)),
+            SALevel(256, (s(2.0, 32, (128, 196, 256)),))),
+        fp=((256, 256), (256, 256), (128, 128)))
+
+
+def rpn_multiclass_heads(base: RpnConfig) -> RpnConfig:
+    """The head / loss / class settings of hf/configs/rpn_multiclass.config:20-36,193-198,256-258 on a given backbone
+    (Car, Pedestrian, Cyclist; per-class search ranges; 'concat' fusion)."""
+    import dataclasses
+    return dataclasses.replace(base, name=base.name + "+multiclass_heads", num_classes=3,
+                               xz_search_range=(3.0, 1.5, 1.5), xz_bin_len=(0.5, 0.25, 0.25),
+                               cluster_sizes=((3.88, 1.63, 1.53), (0.84, 0.66, 1.76), (1.76, 0.6, 1.73)))
+
+
+# ------------------------------------------------------------------------------------------------ backbone
+class _SALevelModule(nn.Module):
+    """One set-abstraction level: FPS once, then every scale's ball query + shared MLP + max (pointnet_util.py:104-286).
+    Single-scale levels concatenate [xyz, features] (:58-60), multi-scale levels [features, xyz] (:264)."""
+
+    def __init__(self, level: SALevel, in_channel: int):
+        super().__init__()
+        self.npoint = level.npoint
+        self.scales = level.scales
+        self.msg = len(level.scales) > 1
+        self.mlps = nn.ModuleList()
+        cout = 0
+        for sc in level.scales:
+            layers, cin = [], in_channel + 3
+            for w in sc.mlp:
+                layers.append(SharedMLPLayer(cin, w))
+                cin = w
+            self.mlps.append(nn.Sequential(*layers))
+            cout += cin
+        self.out_channel = cout
+
+    def geometry(self, xyz):
+        with torch.no_grad():
+            new_xyz = gather_point(xyz, farthest_point_sample(self.npoint, xyz))
+            per_scale = []
+            for sc in self.scales:
+                idx, _, grouped_xyz = query_ball_group(sc.radius, sc.nsample, xyz, new_xyz, center=True)
+                per_scale.append((idx, grouped_xyz))
+        return new_xyz, per_scale
+
+    def forward(self, xyz, points, geom=None):
+        new_xyz, per_scale = geom if geom is not None else self.geometry(xyz)
+        outs = []
+        for (idx, grouped_xyz), mlp in zip(per_scale, self.mlps):
+            grouped = group_concat(points, idx, grouped_xyz, xyz_last=self.msg)    # one pass, rows padded to 4 columns
+            bsz, npt, k, cin = grouped.shape
+            outs.append(shared_mlp(mlp, grouped.reshape(-1, cin), pool_k=k).reshape(bsz, npt, -1))
+        return new_xyz, outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
+
+
+class PointnetBackbone(nn.Module):
+    """hf/core/feature_extractors/pointnet.py: SA levels down, FP levels up (the 'original structure' wiring,
+    :108-128), then conv1d + BN + ReLU layers with dropout between them (:131-151)."""
+
+    def __init__(self, cfg: RpnConfig):
+        super().__init__()
+        self.sa = nn.ModuleList()
+        chans = [cfg.in_channel]
+        for level in cfg.sa:
+            m = _SALevelModule(level, chans[-1])
+            self.sa.append(m)
+            chans.append(m.out_channel)
+        self.fp = nn.ModuleList()
+        c = chans[-1]
+        for i, widths in enumerate(cfg.fp):                    # deepest first
+            skip = chans[len(cfg.sa) - 1 - i]
+            m = PointnetFPModule(c + skip, list(widths))
+            self.fp.append(m)
+            c = m.out_channel
+        fcs = []
+        self.fc_keep = []
+        for (w, keep) in cfg.backbone_fc:
+            fcs.append(SharedMLPLayer(c, w))
+            self.fc_keep.append(keep)
+            c = w
+        self.fc = nn.ModuleList(fcs)
+        self.out_channel = c
+
+    def geometry(self, xyz):
+        """everything that depends on the coordinates only (runs ahead of the features: pipeline.GeometryPrefetcher)"""
+        sa, xyzs = [], [xyz]
+        for m in self.sa:
+            g = m.geometry(xyzs[-1])
+            sa.append(g)
+            xyzs.append(g[0])
+        fp = []
+        for i in range(len(self.fp)):
+            d = len(self.sa) - 1 - i
+            fp.append(PointnetFPModule.geometry(xyzs[d], xyzs[d + 1]))
+        return {"sa": sa, "fp": fp}
+
+    def forward(self, xyz, points, geometry=None):
+        geometry = geometry if geometry is not None else self.geometry(xyz)
+        xyzs, feats = [xyz], [points]
+        for li, m in enumerate(self.sa):
+            nx, nf = m(xyzs[-1], feats[-1], geometry["sa"][li])
+            xyzs.append(nx)
+            feats.append(nf)
+        up = feats[-1]
+        for i, m in enumerate(self.fp):
+            d = len(self.sa) - 1 - i
+            up = m(xyzs[d], xyzs[d + 1], feats[d], up, geometry["fp"][i])
+        b, n, c = up.shape
+        x = up.reshape(-1, c)
+        for li, layer in enumerate(self.fc):
+            x = layer(x)
+            if li != len(self.fc) - 1:
+                x = F.dropout(x, p=1.0 - self.fc_keep[li], training=self.training)   # tf_util.dropout(keep_prob), :146-151
+        return x.reshape(b, n, -1)
+
+
+# ------------------------------------------------------------------------------------------------ heads
+class DenseEluBN(nn.Module):
+    """pointfly.dense (pointfly.py:480-497): linear (no bias under BN) -> activation -> tf.layers.batch_normalization
+    (momentum 0.99, epsilon 1e-3, pointfly.py:371-380).  activation=None for the output layer (rpn_model.py:571-578)."""
+
+    def __init__(self, cin, cout, activation=True):
+        super().__init__()
+        self.linear = nn.Linear(cin, cout, bias=False)
+        nn.init.xavier_normal_(self.linear.weight)                 # glorot_normal_initializer
+        self.bn = BatchNormReLU(cout, eps=1e-3, momentum=0.01, relu=False)   # the HIP statistics / apply / backward passes
+        self.activation = activation
+
+    def forward(self, x):
+        y = self.linear(x)
+        if self.activation:
+            y = F.elu(y)
+        return self.bn(y)
+
+
+class RpnHeads(nn.Module):
+    def __init__(self, cfg: RpnConfig, cin: int):
+        super().__init__()
+        self.cfg = cfg
+        k = cfg.num_classes
+        self.seg = nn.Linear(cin, k + 1)                           # with_bn=False, activation=None: plain dense with bias
+        nn.init.xavier_normal_(self.seg.weight)
+        nn.init.zeros_(self.seg.bias)
+        c = cin if cfg.fusion != "concat" else cin + cfg.img_channels
+        layers = []
+        self.drop = []
+        for (w, rate) in cfg.rpn_fc:
+            layers.append(DenseEluBN(c, w))
+            self.drop.append(rate)
+            c = w
+        self.fc = nn.ModuleList(layers)
+        self.out = DenseEluBN(c, cfg.head_width * k, activation=False)
+
+    def forward(self, pc_fts, proj_img_fts=None):
+        b, p, c = pc_fts.shape
+        seg_logits = self.seg(pc_fts)                              # (B,P,K+1)
+        x = pc_fts
+        if self.cfg.fusion != "none":
+            x = fuse_point_image_features(pc_fts, proj_img_fts, self.cfg.fusion)
+        x = x.reshape(b * p, -1)
+        for layer, rate in zip(self.fc, self.drop):
+            x = F.dropout(layer(x), p=rate, training=self.training)     # tf.layers.dropout(rate)
+        out = self.out(x).reshape(b, p, self.cfg.num_classes, self.cfg.head_width)
+        return seg_logits, out
+
+
+def parse_rpn_output(out, nbx, nbz, nbt):
+    """rpn_model.py:870-935: (B,P,K,D) -> bin_x logits, res_x, bin_z logits, res_z, bin_theta logits, res_theta, res_y, res_size"""
+    o = 0
+    parts = []
+    for w in (nbx, nbx, nbz, nbz, nbt, nbt, 1, 3):
+        parts.append(out[..., o:o + w])
+        o += w
+    parts[6] = parts[6].squeeze(-1)
+    return parts
+
+
+# ------------------------------------------------------------------------------------------------ labels and targets
+def point_labels(xyz, boxes_3d, box_cls):
+    """Per-point class and box (the RPN's label_segs / label_regs): a point takes the FIRST ground-truth box that contains
+    it (kitti_dataset.py:416-440 loops over the objects and overwrites nothing once set), class 0 = background.
+    xyz (B,P,3); boxes_3d (B,G,7) [x,y,z,l,w,h,ry] with y the bottom (camera y down); box_cls (B,G) in 1..K, 0 = padding."""
+    rel = xyz.unsqueeze(2) - boxes_3d[:, None, :, 0:3]                       # (B,P,G,3)
+    c, s = torch.cos(boxes_3d[..., 6])[:, None], torch.sin(boxes_3d[..., 6])[:, None]
+    lx = c * rel[..., 0] - s * rel[..., 2]                                   # rotate by -ry about y into the box frame
+    lz = s * rel[..., 0] + c * rel[..., 2]
+    l, w, h = boxes_3d[:, None, :, 3], boxes_3d[:, None, :, 4], boxes_3d[:, None, :, 5]
+    inside = (lx.abs() <= l / 2) & (lz.abs() <= w / 2) & (rel[..., 1] <= 0) & (rel[..., 1] >= -h) & (box_cls[:, None, :] > 0)
+    first = torch.argmax(inside.to(torch.int8), dim=2)                       # first True (0 when none)
+    any_in = inside.any(dim=2)
+    label_cls = torch.where(any_in, torch.gather(box_cls, 1, first), torch.zeros_like(first))
+    label_reg = torch.gather(boxes_3d, 1, first.unsqueeze(-1).expand(-1, -1, 7)) * any_in.unsqueeze(-1)
+    return label_cls, label_reg
+
+
+def rpn_targets(cfg: RpnConfig, xyz, label_cls, label_reg):
+    """rpn_model.py:733-776: mean sizes of the labelled class, tf_encode around the point (one HIP kernel), then the row of
+    the labelled class.  Background points get class index 0: they are masked out of every box loss."""
+    k = cfg.num_classes
+    cls0 = torch.clamp(label_cls.long() - 1, min=0)                          # (B,P)
+    sizes = torch.as_tensor(np.asarray(cfg.cluster_sizes, np.float32), device=xyz.device)
+    mean_sizes = sizes[cls0]                                                 # (B,P,3)
+    bin_x, res_x, bin_z, res_z, bin_t, res_t, res_y, res_size = box_codec.encode(
+        xyz, 0, label_reg, mean_sizes, cfg.xz_search_range, cfg.xz_bin_len, cfg.r_theta, cfg.delta_theta, k)
+    pick = lambda t: torch.gather(t, 2, cls0.unsqueeze(-1)).squeeze(-1)
+    return {"cls0": cls0, "bin_x": pick(bin_x).long(), "res_x": pick(res_x), "bin_z": pick(bin_z).long(), "res_z": pick(res_z),
+            "bin_theta": bin_t.long(), "res_theta": res_t, "res_y": res_y, "res_size": res_size}
+
+
+def rpn_loss(cfg: RpnConfig, seg_logits, head, label_cls, targets):
+    """rpn_model.py:1040-1128 with hf/core/losses.py: focal loss on the segmentation softmax (alpha 0.25, gamma 2, summed,
+    x seg_loss_weight, / (B P)); softmax cross-entropy of the x / z / theta bins and smooth-L1 of the five residual groups
+    over the foreground points (summed, / number of foreground points; zero when there is none).  No boolean_mask: the
+    foreground mask multiplies, so shapes are static and nothing synchronises with the host."""
+    b, p, k1 = seg_logits.shape
+    nbx, nbt = cfg.num_bin_xz, cfg.theta_bin_num
+    fg = (label_cls > 0)
+    fgf = fg.to(seg_logits.dtype)
+    # segmentation: -alpha (1 - p_t)^gamma log(p_t) on the true class, p clipped to [1e-7, 1 - 1e-7]
+    prob = torch.softmax(seg_logits, dim=-1)
+    pt = torch.gather(prob, 2, label_cls.long().unsqueeze(-1)).squeeze(-1).clamp(1e-7, 1.0 - 1e-7)
+    seg = (0.25 * (1.0 - pt) ** 2 * (-torch.log(pt))).sum() * cfg.seg_loss_weight / float(b * p)
+    # the labelled class's row of the head
+    cls0 = targets["cls0"]
+    row = torch.gather(head, 2, cls0[:, :, None, None].expand(-1, -1, 1, head.shape[-1])).squeeze(2)   # (B,P,D)
+    bx, rx, bz, rz, bt, rt, ry, rs = parse_rpn_output(row, nbx, nbx, nbt)
+    nfg = fgf.sum()
+    denom = torch.clamp(nfg, min=1.0)
+
+    def ce(logits, target):
+        return (F.cross_entropy(logits.reshape(b * p, -1), target.reshape(-1), reduction="none") * fgf.reshape(-1)).sum()
+
+    cls = (ce(bx, targets["bin_x"]) + ce(bz, targets["bin_z"]) + ce(bt, targets["bin_theta"])) * cfg.cls_loss_weight / denom
+    take = lambda res, bins: torch.gather(res, 2, bins.unsqueeze(-1)).squeeze(-1)        # residual of the TRUE bin (:778-786)
+
+    def sl1(pred, target):
+        d = (pred - target).abs()
+        v = torch.where(d < 1, 0.5 * d * d, d - 0.5)
+        if v.dim() == 3:
+            v = v.sum(-1)
+        return (v * fgf).sum()
+
+    reg = (sl1(take(rx, targets["bin_x"]), targets["res_x"]) + sl1(take(rz, targets["bin_z"]), targets["res_z"]) +
+           sl1(take(rt, targets["bin_theta"]), targets["res_theta"]) + sl1(ry, targets["res_y"]) +
+           sl1(rs, targets["res_size"])) * cfg.reg_loss_weight / denom
+    return seg + cls + reg, {"segmentation": seg.detach(), "bin_classification": cls.detach(), "regression": reg.detach(),
+                             "num_foreground": nfg.detach()}
+
+
+# ------------------------------------------------------------------------------------------------ model
+class RpnModel(nn.Module):
+    def __init__(self, cfg: RpnConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = PointnetBackbone(cfg)
+        self.heads = RpnHeads(cfg, self.backbone.out_channel)
+
+    def geometry(self, xyz):
+        return self.backbone.geometry(xyz)
+
+    def forward(self, xyz, intensity, geometry=None, img_fts=None, calib=None):
+        """xyz (B,P,3), intensity (B,P,1) -> seg logits (B,P,K+1), head (B,P,K,D).  img_fts (B,H,W,C) + calib (B,3,4) feed
+        the fusion when the config has one."""
+        pc_fts = self.backbone(xyz, intensity, geometry)
+        proj = None
+        if self.cfg.fusion != "none":
+            proj = project_gather(xyz, calib, img_fts)
+        return self.heads(pc_fts, proj)
+
+    def loss(self, xyz, seg_logits, head, label_cls, label_reg):
+        with torch.no_grad():
+            targets = rpn_targets(self.cfg, xyz, label_cls, label_reg)
+        return rpn_loss(self.cfg, seg_logits, head, label_cls, targets)
+
+
+def synthetic_ground_truth(rng, batch, boxes_per_frame, cfg: RpnConfig, extent=((-40.0, 40.0), (0.0, 70.0)), ground_y=1.6):
+    """(B,G,7) boxes and (B,G) classes in the KITTI camera frame: bottoms on the ground plane y = ground_y (camera y points
+    down, the LiDAR sits ~1.6 m above the road), sizes around the class means, any heading."""
+    k = cfg.num_classes
+    cls = rng.integers(1, k + 1, (batch, boxes_per_frame))
+    mean = np.asarray(cfg.cluster_sizes, np.float32)[cls - 1]
+    size = np.clip(mean * (1.0 + 0.1 * rng.standard_normal(mean.shape)), 0.3, None)
+    x = rng.uniform(extent[0][0], extent[0][1], (batch, boxes_per_frame))
+    z = rng.uniform(extent[1][0], extent[1][1], (batch, boxes_per_frame))
+    y = np.full_like(x, ground_y)
+    ry = rng.uniform(-np.pi, np.pi, (batch, boxes_per_frame))
+    boxes = np.concatenate([np.stack([x, y, z], -1), size, ry[..., None]], -1).astype(np.float32)
+    return boxes, cls.astype(np.int64)
