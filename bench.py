@@ -348,9 +348,10 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 8 frames per GPU (the reference's own data-parallel mode: the per-rank batch of the config, "
                          "rpn_multiclass.config:206); strong: a global batch of 8 frames split over the ranks")
-    ap.add_argument("--workload", choices=("rpn", "stack"), default="rpn",
-                    help="rpn: the RPN train step of rpn_cars_pointnet_paper.config (the metric's workload); stack: the round-1 "
-                         "workload, BASELINE.json configs[1] (single-scale SA+FP stack, mean loss)")
+    ap.add_argument("--workload", choices=("rpn", "rpn_multiclass", "stack"), default="rpn",
+                    help="rpn: the RPN train step of rpn_cars_pointnet_paper.config (PointNet++ MSG backbone); rpn_multiclass: the "
+                         "RPN train step of rpn_multiclass.config (PointCNN backbone, three classes); stack: the round-1 workload, "
+                         "BASELINE.json configs[1] (single-scale SA+FP stack, mean loss)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-table", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the geometry ops inline instead of one step ahead")
@@ -448,19 +449,26 @@ def main():
     rng = np.random.default_rng(1000 + rank)                   # rank-sharded synthetic frames
     xyz = torch.from_numpy(kitti_uniform(rng, per_gpu, N0)).cuda()
     intensity = torch.from_numpy(rng.uniform(-0.5, 0.5, (per_gpu, N0, 1)).astype(np.float32)).cuda()
-    if args.workload == "rpn":
-        cfg = rpn_mod.rpn_cars_pointnet_paper()
+    if args.workload in ("rpn", "rpn_multiclass"):
+        cfg = rpn_mod.rpn_cars_pointnet_paper() if args.workload == "rpn" else rpn_mod.rpn_multiclass()
         model = rpn_mod.RpnModel(cfg).cuda()
-        # ground truth: 12 cars per frame on the road plane; the per-point class / box labels are made once, as the
+        # ground truth: 12 objects per frame on the road plane; the per-point class / box labels are made once, as the
         # reference's data loader makes them on the host (kitti_dataset.py:416-440)
         gt_boxes, gt_cls = rpn_mod.synthetic_ground_truth(rng, per_gpu, 12, cfg, ground_y=3.0)
         label_cls, label_reg = rpn_mod.point_labels(xyz, torch.from_numpy(gt_boxes).cuda(), torch.from_numpy(gt_cls).cuda())
-        levels = [(l.npoint, [(sc.radius, sc.nsample, sc.mlp[-1]) for sc in l.scales]) for l in cfg.sa]
-        nl = len(cfg.sa)   # an FP level interpolates the features of the coarser level: the deepest SA output, then FP outputs
-        fp_channels = [cfg.fp[nl - 2 - lvl][-1] for lvl in range(nl - 1)] + [sum(sc.mlp[-1] for sc in cfg.sa[-1].scales)]
-        workload = ("RPN train step, hf/configs/rpn_cars_pointnet_paper.config point branch: MSG set abstraction 16384->4096->1024->"
-                    "512->64 (nsample 16/32), 4 FP levels, fc 256/256, seg head + bin-based box head (fc 512/512, 76 outputs), "
-                    "targets + focal/softmax/smooth-L1 losses, fwd+bwd+Adam, fp32; image branch not part of the step")
+        if args.workload == "rpn":
+            levels = [(l.npoint, [(sc.radius, sc.nsample, sc.mlp[-1]) for sc in l.scales]) for l in cfg.sa]
+            nl = len(cfg.sa)   # an FP level interpolates the features of the coarser level: the deepest SA output, then FP outputs
+            fp_channels = [cfg.fp[nl - 2 - lvl][-1] for lvl in range(nl - 1)] + [sum(sc.mlp[-1] for sc in cfg.sa[-1].scales)]
+            workload = ("RPN train step, hf/configs/rpn_cars_pointnet_paper.config point branch: MSG set abstraction 16384->4096->1024->"
+                        "512->64 (nsample 16/32), 4 FP levels, fc 256/256, seg head + bin-based box head (fc 512/512, 76 outputs), "
+                        "targets + focal/softmax/smooth-L1 losses, fwd+bwd+Adam, fp32; image branch not part of the step")
+        else:
+            levels, fp_channels = None, None   # the CPU leg of this workload is the kNN / FPS / group chain (cpu_baseline_pointcnn)
+            workload = ("RPN train step, hf/configs/rpn_multiclass.config point branch: PointCNN 5 xconv (K=8; 16384/4096/1024/256/64 "
+                        "points; C 256..1024, X-transformation, global branch) + 6 xdconv layers + fc 256/256, 3 classes, seg head + "
+                        "bin-based box head (fc 512/512, 3x76 outputs), targets + focal/softmax/smooth-L1 losses, fwd+bwd+Adam, fp32; "
+                        "image branch (VGG pyramid + concat fusion) not part of the step")
     else:
         model = modules.PointnetSAFPStack(in_channel=1, sa=SA, fp=FP).cuda()
         levels = [(npoint, [(radius, ns, mlp[-1])]) for (npoint, radius, ns, mlp) in SA]
@@ -482,7 +490,7 @@ def main():
             geo = prefetch.get()
             prefetch.submit(xyz)
         opt.zero_grad(set_to_none=True)
-        if args.workload == "rpn":
+        if args.workload != "stack":
             seg_logits, head = net(xyz, intensity, geometry=geo)
             loss, _ = model.loss(xyz, seg_logits, head, label_cls, label_reg)
         else:
@@ -521,7 +529,7 @@ def main():
         # algorithmic bytes of the two ops at their boundary = 24 641 536 B (the figure `frac` is computed from)
         achieved = SURVEY_TWO_OP_BYTES / (k_us * 1e-6) / 1e9 if k_us else None
         result = {
-            "metric": "KITTI frames/sec RPN train step" if args.workload == "rpn" else "KITTI frames/sec, PointNet++ SA+FP stack train step (fwd+bwd+Adam)",
+            "metric": "KITTI frames/sec RPN train step" if args.workload != "stack" else "KITTI frames/sec, PointNet++ SA+FP stack train step (fwd+bwd+Adam)",
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "ranks": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -547,6 +555,10 @@ def main():
         if not args.no_op_table:
             result["extra"] = per_op_table(hf, xyz8)
         if not args.no_cpu_baseline:
+            if levels is None:   # PointCNN: the CPU chain of the PointNet++ paper config is reported (same ops, other schedule)
+                pc = rpn_mod.rpn_cars_pointnet_paper()
+                levels = [(l.npoint, [(sc.radius, sc.nsample, sc.mlp[-1]) for sc in l.scales]) for l in pc.sa]
+                fp_channels = [pc.fp[len(pc.sa) - 2 - lvl][-1] for lvl in range(len(pc.sa) - 1)] + [1024]
             result["cpu_baseline"] = cpu_baseline(args.cpu_frames, levels, fp_channels)
     dp.shutdown(ctx)
     sys.stdout.flush()

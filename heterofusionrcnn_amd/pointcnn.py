@@ -1,0 +1,222 @@
+"""PointCNN backbone (the `pc_pointcnn` extractor of hf/configs/rpn_multiclass.config:62-118) on the HIP ops.
+
+  xconv        hf/core/feature_extractors/pointcnn.py:16-151   Algorithm 1 of the PointCNN paper
+  PointCNN     pointcnn.py:186-388   encoder of xconv layers (FPS down-sampling), decoder of xdconv layers (an xconv from
+               a coarser layer onto a finer one, concat with the finer layer's encoder features, dense), fc layers
+  layers       hf/core/pointfly.py:371-497   dense / conv2d / depthwise_conv2d / separable_conv2d, every one
+               linear (no bias) -> ELU -> BatchNorm(momentum 0.99, eps 1e-3)
+
+The neighbour search is the HIP kNN kernel (hf_knn_point_sorted: grid binning + ring search, ties to the lower index)
+instead of the reference's dense (B,P,N) distance matrix + tf.nn.top_k (pointfly.py:185-212: 1 GiB per frame at
+P = N = 16384); the neighbourhoods are gathered by hf_group_point (+ its scatter gradient); the sampling is the HIP FPS.
+The convolutions with a (1,K) window over the K neighbours are written as the matrix products they are:
+
+  conv2d(.., K*K, (1,K)) on (B,P,K,3)            = Linear(3K -> K*K) on the flattened [k][c] window        (X_0)
+  depthwise_conv2d(.., K, (1,K)) on (B,P,K,K)    = out[c*K + m] = sum_w in[w][c] * W[w][c][m]                (X_1, X_2)
+  separable_conv2d(.., C, (1,K), dm) on (B,P,K,Cin) = depthwise out[c*dm + m] = sum_k in[k][c] * Wd[k][c][m],
+                                                      then Linear(Cin*dm -> C)                              (fts_conv)
+
+The weight layouts are TensorFlow's (HWIO / depthwise HW, in, multiplier) so that a checkpoint would map one to one;
+tests/test_pointcnn.py checks the einsum forms against torch.nn.functional.conv2d with the same weights.
+TensorFlow cannot be imported here: parity unpinned against reference outputs.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .grouping import group_point, knn_point
+from .sampling import farthest_point_sample, gather_point
+from .mlp import BatchNormReLU
+
+
+class EluBN(nn.Module):
+    """activation (ELU or none) then tf.layers.batch_normalization(momentum 0.99, epsilon 1e-3) over the last dimension"""
+
+    def __init__(self, channels, activation=True):
+        super().__init__()
+        self.bn = BatchNormReLU(channels, eps=1e-3, momentum=0.01, relu=False)
+        self.activation = activation
+
+    def forward(self, x):
+        shape = x.shape
+        x = x.reshape(-1, shape[-1])
+        if self.activation:
+            x = F.elu(x)
+        return self.bn(x).reshape(shape)
+
+
+class Dense(nn.Module):
+    """pf.dense: Linear without bias -> ELU -> BN"""
+
+    def __init__(self, cin, cout, activation=True):
+        super().__init__()
+        self.linear = nn.Linear(cin, cout, bias=False)
+        nn.init.xavier_normal_(self.linear.weight)
+        self.post = EluBN(cout, activation)
+
+    def forward(self, x):
+        return self.post(self.linear(x))
+
+
+def depthwise_k(x, weight):
+    """x (.., K, C), weight (K, C, M) (TensorFlow's depthwise filter (1, K, C, M) without the unit height) -> (.., C*M):
+    a VALID depthwise convolution with a (1, K) window over a width-K input leaves one position, channel c*M + m"""
+    y = torch.einsum("...wc,wcm->...cm", x, weight)
+    return y.reshape(*y.shape[:-2], -1)
+
+
+class DepthwiseK(nn.Module):
+    """pf.depthwise_conv2d(x, K, (1,K)) on x (.., K, C): weight (K_w, C, M), out (.., C*M) with out[c*M + m]"""
+
+    def __init__(self, k, channels, multiplier, activation=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(k, channels, multiplier))
+        nn.init.xavier_normal_(self.weight.view(k, channels * multiplier))
+        self.post = EluBN(channels * multiplier, activation)
+
+    def forward(self, x):
+        return self.post(depthwise_k(x, self.weight))
+
+
+class SeparableK(nn.Module):
+    """pf.separable_conv2d(x, C, (1,K), depth_multiplier): depthwise over the K neighbours, pointwise to C, ELU, BN
+    (tf.layers.separable_conv2d applies the activation after the pointwise convolution only)"""
+
+    def __init__(self, k, cin, cout, multiplier):
+        super().__init__()
+        self.depthwise = nn.Parameter(torch.empty(k, cin, multiplier))
+        nn.init.xavier_normal_(self.depthwise.view(k, cin * multiplier))
+        self.pointwise = nn.Linear(cin * multiplier, cout, bias=False)
+        nn.init.xavier_normal_(self.pointwise.weight)
+        self.post = EluBN(cout, True)
+
+    def forward(self, x):                                    # (B,P,K,Cin)
+        return self.post(self.pointwise(depthwise_k(x, self.depthwise)))
+
+
+class XConv(nn.Module):
+    """pointcnn.py:16-151.  pts (B,N,3), fts (B,N,Cprev) or None, qrs (B,P,3) -> (B,P,C) (+ C//4 with_global)"""
+
+    def __init__(self, k, dilation, c_prev, c, c_pts_fts, depth_multiplier, with_x=True, with_global=False):
+        super().__init__()
+        self.k, self.d = k, dilation
+        self.lift0 = Dense(3, c_pts_fts)
+        self.lift1 = Dense(c_pts_fts, c_pts_fts)
+        cin = c_pts_fts + c_prev
+        self.with_x = with_x
+        if with_x:
+            self.x0 = Dense(3 * k, k * k)                    # conv2d (1,K) over the [k][c] window
+            self.x1 = DepthwiseK(k, k, k)
+            self.x2 = DepthwiseK(k, k, k, activation=False)
+        self.conv = SeparableK(k, cin, c, depth_multiplier)
+        self.with_global = with_global
+        if with_global:
+            self.g0 = Dense(3, c // 4)
+            self.g1 = Dense(c // 4, c // 4)
+        self.out_channel = c + (c // 4 if with_global else 0)
+
+    def neighbours(self, pts, qrs):
+        """knn_indices_general(qrs, pts, K*D)[:, :, ::D] (pointcnn.py:72-73): coordinates only"""
+        with torch.no_grad():
+            _, idx = knn_point(self.k * self.d, pts, qrs)
+            return idx[:, :, ::self.d].contiguous() if self.d > 1 else idx
+
+    def forward(self, pts, fts, qrs, idx=None):
+        idx = idx if idx is not None else self.neighbours(pts, qrs)
+        b, p, k = idx.shape
+        local = group_point(pts, idx) - qrs.unsqueeze(2)     # (B,P,K,3)  P' <- P - p
+        f = self.lift1(self.lift0(local))                     # F_delta
+        if fts is not None:
+            f = torch.cat([f, group_point(fts, idx)], dim=-1)  # F_* <- [F_delta, F]
+        if self.with_x:
+            x = self.x0(local.reshape(b, p, 1, k * 3)).reshape(b, p, k, k)
+            x = self.x1(x).reshape(b, p, k, k)
+            x = self.x2(x).reshape(b, p, k, k)
+            f = torch.matmul(x, f)                            # F_X <- X x F_*
+        out = self.conv(f)                                    # (B,P,C)
+        if self.with_global:
+            out = torch.cat([self.g1(self.g0(qrs)), out], dim=-1)
+        return out
+
+
+@dataclass
+class PointCnnConfig:
+    """xconv_param = (K, D, P, C); xdconv_param = (K, D, pts_layer_idx, qrs_layer_idx) -- rpn_multiclass.config:67-112"""
+    xconv: Tuple[Tuple[int, int, int, int], ...] = ((8, 1, -1, 256), (8, 1, 4096, 256), (8, 1, 1024, 512), (8, 1, 256, 1024),
+                                                    (8, 1, 64, 1024))
+    xdconv: Tuple[Tuple[int, int, int, int], ...] = ((8, 1, 4, 4), (8, 1, 4, 3), (8, 1, 3, 2), (8, 1, 2, 1), (8, 1, 1, 0),
+                                                     (8, 1, 0, 0))
+    fc: Tuple[Tuple[int, float], ...] = ((256, 0.5), (256, 0.5))
+    in_channel: int = 1
+    with_x: bool = True
+    with_global: bool = True
+
+
+class PointCnnBackbone(nn.Module):
+    """pointcnn.py:186-388 (sampling 'fps', multi_scale_grouping off)"""
+
+    def __init__(self, cfg: PointCnnConfig = PointCnnConfig()):
+        super().__init__()
+        self.cfg = cfg
+        self.enc = nn.ModuleList()
+        chans = [cfg.in_channel]
+        for li, (k, d, p, c) in enumerate(cfg.xconv):
+            if li == 0:
+                c_pts, dm, c_prev = (c // 2 if cfg.in_channel == 0 else c // 4), 4, cfg.in_channel      # :259-261
+            else:
+                c_before = cfg.xconv[li - 1][3]
+                c_pts, dm, c_prev = c_before // 4, math.ceil(c / c_before), chans[-1]                     # :262-265
+            m = XConv(k, d, c_prev, c, c_pts, dm, cfg.with_x, cfg.with_global and li == len(cfg.xconv) - 1)
+            self.enc.append(m)
+            chans.append(m.out_channel)
+        self.dec = nn.ModuleList()
+        self.fuse = nn.ModuleList()
+        c_last = chans[-1]
+        for li, (k, d, pi, qi) in enumerate(cfg.xdconv):
+            c = cfg.xconv[qi][3]
+            c_prev = cfg.xconv[pi][3]
+            fts_c = chans[pi + 1] if li == 0 else c_last                                                 # :318-322
+            self.dec.append(XConv(k, d, fts_c, c, c_prev // 4, 1, cfg.with_x, False))                     # :326-348
+            self.fuse.append(Dense(c + chans[qi + 1], c))                                                # :349-352
+            c_last = c
+        self.fc = nn.ModuleList()
+        self.fc_drop = []
+        for (w, rate) in cfg.fc:
+            self.fc.append(Dense(c_last, w))
+            self.fc_drop.append(rate)
+            c_last = w
+        self.out_channel = c_last
+
+    def geometry(self, xyz):
+        """layer points (FPS) and every neighbour table: functions of the coordinates alone"""
+        with torch.no_grad():
+            pts = [xyz]
+            enc_idx = []
+            for li, (k, d, p, c) in enumerate(self.cfg.xconv):
+                cur = pts[-1]
+                same = p == -1 or (li > 0 and p == self.cfg.xconv[li - 1][2])                             # :215-218
+                qrs = cur if same else gather_point(cur, farthest_point_sample(p, cur))
+                enc_idx.append(self.enc[li].neighbours(cur, qrs))
+                pts.append(qrs)
+            dec_idx = [self.dec[li].neighbours(pts[pi + 1], pts[qi + 1]) for li, (k, d, pi, qi) in enumerate(self.cfg.xdconv)]
+        return {"pts": pts, "enc": enc_idx, "dec": dec_idx}
+
+    def forward(self, xyz, features, geometry=None):
+        g = geometry if geometry is not None else self.geometry(xyz)
+        pts = g["pts"]
+        fts = [features]
+        for li, m in enumerate(self.enc):
+            fts.append(m(pts[li], fts[-1], pts[li + 1], g["enc"][li]))
+        cur = None
+        for li, (k, d, pi, qi) in enumerate(self.cfg.xdconv):
+            src = fts[pi + 1] if li == 0 else cur
+            x = self.dec[li](pts[pi + 1], src, pts[qi + 1], g["dec"][li])
+            cur = self.fuse[li](torch.cat([x, fts[qi + 1]], dim=-1))
+        out = cur
+        for layer, rate in zip(self.fc, self.fc_drop):
+            out = F.dropout(layer(out), p=rate, training=self.training)                                   # :371-384
+        return out

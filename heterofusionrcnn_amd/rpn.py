@@ -65,6 +65,8 @@ class RpnConfig:
     theta_search_range: float = 1.0                                        # fraction of pi
     theta_bin_num: int = 12
     cluster_sizes: Tuple[Tuple[float, float, float], ...] = ((3.9, 1.6, 1.5),)   # mean (l, w, h) per class
+    backbone: str = "pointnet"                                             # 'pointnet' (sa / fp / backbone_fc) | 'pointcnn'
+    pointcnn: Optional[object] = None                                      # pointcnn.PointCnnConfig for backbone 'pointcnn'
     fusion: str = "none"                                                   # 'mean' | 'concat' | 'none' (no image branch)
     img_channels: int = 0
     seg_loss_weight: float = 100.0
@@ -110,6 +112,17 @@ def rpn_stack_config2() -> RpnConfig:
         sa=(SALevel(4096, (s(0.5, 32, (32, 32, 64)),)), SALevel(1024, (s(1.0, 32, (64, 96, 128)),)),
             SALevel(256, (s(2.0, 32, (128, 196, 256)),))),
         fp=((256, 256), (256, 256), (128, 128)))
+
+
+def rpn_multiclass(img_channels: int = 0) -> RpnConfig:
+    """hf/configs/rpn_multiclass.config: the PointCNN extractor (:62-118), three classes with their own search ranges
+    (:20-36), 'concat' fusion with the image branch's features when a feature map is supplied (img_channels > 0)."""
+    from .pointcnn import PointCnnConfig
+    import dataclasses
+    base = RpnConfig(name="rpn_multiclass", backbone="pointcnn", pointcnn=PointCnnConfig(),
+                     fusion="concat" if img_channels else "none", img_channels=img_channels)
+    heads = rpn_multiclass_heads(base)
+    return dataclasses.replace(heads, name="rpn_multiclass")
 
 
 def rpn_multiclass_heads(base: RpnConfig) -> RpnConfig:
@@ -360,7 +373,11 @@ class RpnModel(nn.Module):
     def __init__(self, cfg: RpnConfig):
         super().__init__()
         self.cfg = cfg
-        self.backbone = PointnetBackbone(cfg)
+        if cfg.backbone == "pointcnn":
+            from .pointcnn import PointCnnBackbone
+            self.backbone = PointCnnBackbone(cfg.pointcnn)
+        else:
+            self.backbone = PointnetBackbone(cfg)
         self.heads = RpnHeads(cfg, self.backbone.out_channel)
 
     def geometry(self, xyz):

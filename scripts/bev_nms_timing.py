@@ -1,0 +1,29 @@
+"""compute_bev_iou at 70 000 x 64 (BASELINE config 3) and oriented_nms at 9000 boxes (rpn pre_nms_size): bursts for
+`rocprofv3 --kernel-trace` (scripts/parse_trace.py splits bev_iou_kernel / nms_mask_kernel / nms_sweep_kernel)."""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import heterofusionrcnn_amd as hf
+from bench import rand_bev, time_op
+rng = np.random.default_rng(3)
+a = torch.from_numpy(rand_bev(rng, 70000)).cuda()
+g = torch.from_numpy(rand_bev(rng, 64)).cuda()
+res = {"bev_iou_70000x64_us": round(time_op(lambda: hf.compute_bev_iou(a, g), iters=50), 2)}
+res["bev_iou_Gboxpairs_per_s"] = round(70000 * 64 / res["bev_iou_70000x64_us"] / 1e3, 1)
+for seed, thresh in ((4, 0.8), (4, 0.01)):
+    r2 = np.random.default_rng(seed)
+    base = rand_bev(r2, 300)
+    boxes = np.repeat(base, 30, 0)
+    boxes[:, [0, 2]] += r2.normal(0, 0.3, (9000, 1)).astype(np.float32)
+    boxes[:, [1, 3]] += r2.normal(0, 0.3, (9000, 1)).astype(np.float32)
+    boxes[:, 4] += r2.normal(0, 0.1, 9000).astype(np.float32)
+    nb = torch.from_numpy(boxes.astype(np.float32)).cuda()
+    res["oriented_nms_9000_clustered_t%.2f_us" % thresh] = round(time_op(lambda: hf.oriented_nms(nb, thresh), iters=10, warm=2), 1)
+nb = torch.from_numpy(rand_bev(rng, 9000)).cuda()
+res["oriented_nms_9000_uniform_t0.80_us"] = round(time_op(lambda: hf.oriented_nms(nb, 0.8), iters=10, warm=2), 1)
+print(json.dumps(res, indent=1))
+if os.environ.get("PHASES"):
+    for stop in (1, 2, 3, 4, 0):
+        os.environ["HF_BEV_STOP"] = str(stop)
+        print("bev_iou stop", stop, round(time_op(lambda: hf.compute_bev_iou(a, g), iters=50), 2), "us")
+    os.environ.pop("HF_BEV_STOP")

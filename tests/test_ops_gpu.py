@@ -549,6 +549,21 @@ def test_full_size_headline_ball_group(hf, oracle_mod):
     dist, i3 = hf.three_nn(x, new_xyz)
     od, oi3 = oracle_mod.three_nn(xyz, q)
     assert np.array_equal(host(i3), oi3) and np.array_equal(host(dist), od)
+    # levels 2 and 3 of the config-2 stack at full size: 4096 -> 1024 (r = 1.0), 1024 -> 256 (r = 2.0), K = 32
+    lvl_x, lvl_np = new_xyz, q
+    for npoint, r in ((1024, 1.0), (256, 2.0)):
+        f = hf.farthest_point_sample(npoint, lvl_x)
+        assert np.array_equal(host(f), oracle_mod.farthest_point_sample(npoint, lvl_np))
+        nx = hf.gather_point(lvl_x, f)
+        nq = host(nx)
+        idx, cnt, gx = hf.query_ball_group(r, 32, lvl_x, nx, center=True)
+        oi, oc = oracle_mod.query_ball_point(r, 32, lvl_np, nq)
+        assert np.array_equal(host(idx), oi) and np.array_equal(host(cnt), oc), (npoint, r)
+        assert np.array_equal(host(gx), oracle_mod.group_point(lvl_np, oi) - nq[:, :, None, :])
+        d3, j3 = hf.three_nn(lvl_x, nx)
+        od3, oj3 = oracle_mod.three_nn(lvl_np, nq)
+        assert np.array_equal(host(j3), oj3) and np.array_equal(host(d3), od3)
+        lvl_x, lvl_np = nx, nq
 
 
 def test_full_size_bev_iou_properties(hf):
@@ -642,8 +657,16 @@ def test_reference_kernels_grouping_sampling(hf):
 
 def test_reference_kernels_bev_iou(hf, oracle_mod):
     R = _ref_gpu()
-    rng = np.random.default_rng(22)
-    a = _clustered(rng, 60, 10)
+    # a fixture whose pairwise a x a IoUs (the ones NMS compares) all keep a margin from both thresholds: the keep
+    # vector then cannot depend on the last ulps of sinf / cosf / atan2f, and equality is asserted unconditionally
+    for seed in range(22, 60):
+        rng = np.random.default_rng(seed)
+        a = _clustered(rng, 60, 10)
+        self_iou = oracle_mod.compute_bev_iou(a, a)[1]
+        if all(not np.any(np.abs(self_iou - t) < 1e-4) for t in (0.7, 0.05)):
+            break
+    else:
+        raise AssertionError("no margin-safe fixture found")
     b = a[:64].copy()
     ad, bd = dev(a), dev(b)
     ref_ov = torch.zeros((len(a), len(b)), device="cuda")
@@ -661,11 +684,9 @@ def test_reference_kernels_bev_iou(hf, oracle_mod):
         assert R.hfref_nms_mask(_p(ad), _p(ref_mask), n, ctypes.c_float(thresh)) == 0
         want, kept = oracle_mod.nms_sweep(host(ref_mask).view(np.uint64))
         keep, num = hf.oriented_nms(ad, thresh, return_count=True)
-        if not np.array_equal(host(keep), want):
-            assert (torch.abs(ref_iou - thresh) < TOL).any(), "keep differs from the reference kernels"
-        else:
-            assert int(host(num)[0]) == kept
-            assert torch.equal(hf.nms_mask(ad, thresh), ref_mask)
+        assert np.array_equal(host(keep), want), "keep differs from the reference kernels"
+        assert int(host(num)[0]) == kept
+        assert torch.equal(hf.nms_mask(ad, thresh), ref_mask)
 
 
 def test_reference_kernels_crop(hf):
@@ -833,6 +854,102 @@ def test_sa_module_composition_against_oracle(hf, oracle_mod):
             h = torch.relu(bn(torch.nn.functional.linear(h, layer.fc.weight, layer.fc.bias)))
         refs.append(h.view(2, 128, ns, -1).max(dim=2).values)
     torch.testing.assert_close(out2, torch.cat(refs, dim=-1), rtol=2e-4, atol=5e-5)
+
+
+def test_fp_module_composition_against_oracle(hf, oracle_mod):
+    """pointnet_fp_module restated from pointnet_util.py:289-330: three_nn -> dist = max(dist, 1e-10) -> w = (1/d) / sum(1/d)
+    -> three_interpolate -> concat [interpolated, points1] -> conv2d 1x1 + BN + ReLU.  The oracle runs the ops, numpy the
+    weights / concat / MLP (batch statistics, eps 1e-3)."""
+    from heterofusionrcnn_amd import modules
+    rng = np.random.default_rng(9)
+    for (n, m, c1, c2, widths) in ((1024, 256, 5, 16, (24, 8)), (700, 3, 0, 7, (6,))):
+        xyz1 = rng.random((2, n, 3), dtype=np.float32)
+        xyz2 = xyz1[:, rng.permutation(n)[:m]].copy()          # known points are a subset: exact zeros among the distances
+        p1 = rng.standard_normal((2, n, c1)).astype(np.float32) if c1 else None
+        p2 = rng.standard_normal((2, m, c2)).astype(np.float32)
+        torch.manual_seed(n)
+        fp = modules.PointnetFPModule(c1 + c2, list(widths)).cuda().train()
+        out = fp(dev(xyz1), dev(xyz2), dev(p1) if c1 else None, dev(p2))
+        dist, idx = oracle_mod.three_nn(xyz1, xyz2)
+        d = np.maximum(dist, np.float32(1e-10))
+        w = (np.float32(1.0) / d) / (np.float32(1.0) / d).sum(axis=2, keepdims=True)
+        interp = oracle_mod.three_interpolate(p2, idx, w.astype(np.float32))
+        x = np.concatenate([interp, p1], axis=2) if c1 else interp           # [interpolated, points1] (:311-313)
+        # the composition up to the MLP, bit for bit: the module's own pieces on the same inputs
+        gi, gw, ginv = modules.PointnetFPModule.geometry(dev(xyz1), dev(xyz2))
+        assert np.array_equal(host(gi), idx)
+        np.testing.assert_allclose(host(gw), w, rtol=0, atol=1e-6)
+        pre = hf.three_interpolate(dev(p2), gi, gw)
+        np.testing.assert_allclose(host(pre), interp, rtol=0, atol=1e-5)
+        h = x.reshape(-1, x.shape[-1]).astype(np.float64)
+        for layer in fp.mlp:
+            z = h @ host(layer.fc.weight).T.astype(np.float64) + host(layer.fc.bias)
+            z = (z - z.mean(0)) / np.sqrt(z.var(0) + 1e-3) * host(layer.bn.weight) + host(layer.bn.bias)
+            h = np.maximum(z, 0.0)
+        np.testing.assert_allclose(host(out).reshape(-1, widths[-1]), h, rtol=2e-4, atol=2e-4)
+
+
+def test_full_size_config2_stack_fwd_bwd_against_op_by_op_form(hf):
+    """BASELINE config 2 at full size (B=8, 16384 -> 4096 -> 1024 -> 256, K=32, fp32): the fused path (grouped geometry,
+    group_concat, MFMA linear/BN/ReLU(+max-pool) nodes, interpolate+concat, gather-form gradients) against the op-by-op
+    torch form that materialises what the reference materialises (group_point -> concat -> 1x1 conv -> BN -> ReLU -> max;
+    three_interpolate -> concat -> ...), same weights: output and every parameter gradient"""
+    from heterofusionrcnn_amd import modules
+    from heterofusionrcnn_amd.modules import three_nn_weights
+    F = torch.nn.functional
+    torch.manual_seed(5)
+    rng = np.random.default_rng(5)
+    xyz = dev(kitti_uniform(rng, 8, 16384))
+    inten = dev(rng.uniform(-0.5, 0.5, (8, 16384, 1)).astype(np.float32))
+    model = modules.PointnetSAFPStack(in_channel=1).cuda().train()
+
+    def layer_ref(layer, x):
+        z = F.linear(x, layer.fc.weight, layer.fc.bias)
+        mu, var = z.mean(0), z.var(0, unbiased=False)
+        return torch.relu((z - mu) / torch.sqrt(var + 1e-3) * layer.bn.weight + layer.bn.bias)
+
+    def stack_ref(xyz, pts):
+        xyzs, feats = [xyz], [pts]
+        for m in model.sa:
+            new_xyz = hf.gather_point(xyzs[-1], hf.farthest_point_sample(m.npoint, xyzs[-1]))
+            idx, _ = hf.query_ball_point(m.radius, m.nsample, xyzs[-1], new_xyz)
+            g = torch.cat([hf.group_point(xyzs[-1], idx) - new_xyz.unsqueeze(2), hf.group_point(feats[-1], idx)], -1)
+            b_, n_, k_, c_ = g.shape
+            x = g.reshape(-1, c_)
+            for layer in m.mlp:
+                x = layer_ref(layer, x)
+            xyzs.append(new_xyz)
+            feats.append(x.reshape(b_, n_, k_, -1).max(2).values)
+        up = feats[-1]
+        for i, m in enumerate(model.fp):
+            d = len(model.sa) - 1 - i
+            dist, idx = hf.three_nn(xyzs[d], xyzs[d + 1])
+            x = torch.cat([hf.three_interpolate(up, idx, three_nn_weights(dist)), feats[d]], 2)
+            b_, n_, c_ = x.shape
+            x = x.reshape(-1, c_)
+            for layer in m.mlp:
+                x = layer_ref(layer, x)
+            up = x.reshape(b_, n_, -1)
+        return up
+
+    g_out = dev(np.random.default_rng(6).standard_normal((8, 16384, model.out_channel)).astype(np.float32)) / 16384.0
+    params = list(model.parameters())
+    out = model(xyz, inten, geometry=model.geometry(xyz))
+    grads = torch.autograd.grad(out, params, g_out, allow_unused=True)
+    ref = stack_ref(xyz, inten)
+    grads_ref = torch.autograd.grad(ref, params, g_out, allow_unused=True)
+    torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3)
+    # Gradients of a BatchNorm stack over 10^5..10^6 rows carry fp32 noise of their own: against an fp64 evaluation of
+    # the same graph the op-by-op fp32 form is off by up to 0.35 % of a parameter's largest component, the fused path by up
+    # to 2 % (scripts/probes/grad_noise_probe.py).  Bound: 3 % of the largest component of each parameter's gradient.
+    for (name, _), a, b in zip(model.named_parameters(), grads, grads_ref):
+        if a is None or b is None or name.endswith("fc.bias"):
+            # a bias in front of a BatchNorm has an exactly-zero gradient analytically: the fused node returns zeros,
+            # autograd through the op-by-op form returns rounding noise
+            assert (a is None or float(a.abs().max()) < 1e-3) and (b is None or float(b.abs().max()) < 1e-3), name
+            continue
+        scale = float(b.abs().max()) + 1e-7
+        assert float((a - b).abs().max()) <= 3e-2 * scale + 1e-6, (name, float((a - b).abs().max()), scale)
 
 
 def test_iou3d_and_nms_adapters(hf, oracle_mod):
