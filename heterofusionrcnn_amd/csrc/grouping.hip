@@ -10,6 +10,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "hf_common.h"
 
 namespace hf {
@@ -130,6 +132,40 @@ __global__ void group_point_kernel(int n, int c, long long rows_per_batch, long 
         const int ii = idx[row];
         const vec_t v = *reinterpret_cast<const vec_t *>(points + (bb * n + ii) * c + l * VEC);
         *reinterpret_cast<vec_t *>(out + row * c + l * VEC) = v;
+    }
+}
+
+// The same op when c / 4 is a power of two (c = 16 .. 1024): no integer division (lane -> row by a shift, the batch is
+// grid.y), ROWS rows per thread in flight (index loads, then ROWS independent 16-byte gathers before the first store),
+// nontemporal stores for the write-once output so that the feature table stays in the XCD's L2.
+template <int ROWS>
+__global__ __launch_bounds__(256) void group_point_pow2_kernel(int nbatch, int n, int c, int cv_shift, int rows_per_batch,
+                                                               const float *__restrict__ points,
+                                                               const int *__restrict__ idx, float *__restrict__ out)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    // linear workgroup id = cloud + b * chunk: workgroups are dealt round-robin over the 8 XCDs, so with b a multiple of 8
+    // every workgroup of a cloud runs on ONE XCD and that cloud's table stays in its 4 MB L2 (speed only)
+    const int bb = blockIdx.x % nbatch;
+    const unsigned gxb = gridDim.x / nbatch;
+    const unsigned tid = (blockIdx.x / nbatch) * 256u + threadIdx.x;
+    const int l = static_cast<int>(tid & ((1u << cv_shift) - 1u));
+    const int rstride = static_cast<int>((gxb * 256u) >> cv_shift);
+    const float *base = points + static_cast<size_t>(bb) * n * c + l * 4;
+    const int *ib = idx + static_cast<size_t>(bb) * rows_per_batch;
+    float *ob = out + static_cast<size_t>(bb) * rows_per_batch * c + l * 4;
+    for (int row0 = static_cast<int>(tid >> cv_shift); row0 < rows_per_batch; row0 += rstride * ROWS) {
+        v4 v[ROWS];
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int row = row0 + i * rstride;
+            v[i] = *reinterpret_cast<const v4 *>(base + static_cast<size_t>(ib[row < rows_per_batch ? row : row0]) * c);
+        }
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int row = row0 + i * rstride;
+            if (row < rows_per_batch) __builtin_nontemporal_store(v[i], reinterpret_cast<v4 *>(ob + static_cast<size_t>(row) * c));
+        }
     }
 }
 
@@ -608,7 +644,16 @@ HF_API int hf_group_point(int b, int n, int c, int m, int nsample, const float *
     const int block = 256;
     hipStream_t st = as_stream(stream);
     const bool al16 = (reinterpret_cast<uintptr_t>(points) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    if (c % 4 == 0 && al16)
+    const int cv = c / 4;
+    if (c % 4 == 0 && al16 && cv >= 4 && cv <= 256 && (cv & (cv - 1)) == 0 && b <= 65535 && rpb * cv < (1LL << 31)) {
+        int cv_shift = 0;
+        while ((1 << cv_shift) < cv) ++cv_shift;
+        long long gx = (rpb * cv + 256 * 4 - 1) / (256 * 4);
+        const long long cap = std::max<long long>(1, (kNumCU * 8) / b);
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL((group_point_pow2_kernel<4>), dim3(static_cast<unsigned>(gx * b)), dim3(256), 0, st, b, n, c, cv_shift,
+                           static_cast<int>(rpb), points, idx, out);
+    } else if (c % 4 == 0 && al16)
         hipLaunchKernelGGL((group_point_kernel<4>), dim3(grid_for(nrows * (c / 4), block)), dim3(block), 0, st, n, c,
                            rpb, nrows, points, idx, out);
     else

@@ -8,6 +8,8 @@
 // result of (float)1e40 is +inf.  So fp32 accumulators with a +inf sentinel are bit-equivalent.
 #include <math.h>
 
+#include <algorithm>
+
 #include "hf_common.h"
 
 namespace hf {
@@ -115,6 +117,53 @@ __global__ void three_interpolate_cl_kernel(int m, int c, long long n_per_batch,
         const vec_t p2 = *reinterpret_cast<const vec_t *>(base + static_cast<size_t>(k[2]) * c);
         const vec_t r = w[0] * p0 + w[1] * p1 + w[2] * p2;  // left to right, no contraction
         *reinterpret_cast<vec_t *>(out + row * c + l * VEC) = r;
+    }
+}
+
+// The same op when c / 4 is a power of two (c = 16 .. 1024, every width the reference configs use): no integer
+// division anywhere (lane -> row by a shift, the batch is grid.y), ROWS rows per thread in flight (3 * ROWS independent
+// 16-byte gathers before the first use), the write-once output leaves with nontemporal stores so that the points table
+// (a few MB per cloud) stays in the XCD's L2.  Consecutive lanes cover consecutive 16-byte pieces of consecutive rows.
+template <int ROWS>
+__global__ __launch_bounds__(256) void three_interpolate_cl_pow2_kernel(int nbatch, int m, int c, int cv_shift, int n,
+                                                                        const float *__restrict__ points,
+                                                                        const int *__restrict__ idx,
+                                                                        const float *__restrict__ weight,
+                                                                        float *__restrict__ out)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    // linear workgroup id = cloud + b * chunk: workgroups are dealt round-robin over the 8 XCDs, so with b a multiple of 8
+    // every workgroup of a cloud runs on ONE XCD and that cloud's table stays in its 4 MB L2 (speed only)
+    const int bb = blockIdx.x % nbatch;
+    const unsigned gxb = gridDim.x / nbatch;
+    const unsigned tid = (blockIdx.x / nbatch) * 256u + threadIdx.x;
+    const int l = static_cast<int>(tid & ((1u << cv_shift) - 1u));
+    const int rstride = static_cast<int>((gxb * 256u) >> cv_shift);
+    const float *base = points + static_cast<size_t>(bb) * m * c + l * 4;
+    const int *kb = idx + static_cast<size_t>(bb) * n * 3;
+    const float *wb = weight + static_cast<size_t>(bb) * n * 3;
+    float *ob = out + static_cast<size_t>(bb) * n * c + l * 4;
+    for (int row0 = static_cast<int>(tid >> cv_shift); row0 < n; row0 += rstride * ROWS) {
+        v4 p[ROWS][3];
+        float w[ROWS][3];
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int row = row0 + i * rstride;
+            const int rr = row < n ? row : row0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                w[i][t] = wb[rr * 3 + t];
+                p[i][t] = *reinterpret_cast<const v4 *>(base + static_cast<size_t>(kb[rr * 3 + t]) * c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int row = row0 + i * rstride;
+            if (row < n) {
+                const v4 r = w[i][0] * p[i][0] + w[i][1] * p[i][1] + w[i][2] * p[i][2];  // left to right, no contraction
+                __builtin_nontemporal_store(r, reinterpret_cast<v4 *>(ob + static_cast<size_t>(row) * c));
+            }
+        }
     }
 }
 
@@ -345,7 +394,17 @@ HF_API int hf_three_interpolate_cl(int b, int m, int c, int n, const float *poin
     const int block = 256;
     hipStream_t st = as_stream(stream);
     const bool al16 = (reinterpret_cast<uintptr_t>(points) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    if (c % 4 == 0 && al16)
+    const int cv = c / 4;
+    if (c % 4 == 0 && al16 && cv >= 4 && cv <= 256 && (cv & (cv - 1)) == 0 && b <= 65535 && static_cast<long long>(n) * cv < (1LL << 31)) {
+        int cv_shift = 0;
+        while ((1 << cv_shift) < cv) ++cv_shift;
+        // 4 rows in flight per thread; enough workgroups for ~8 per CU across the batch
+        long long gx = (static_cast<long long>(n) * cv + 256 * 4 - 1) / (256 * 4);
+        const long long cap = std::max<long long>(1, (kNumCU * 8) / b);
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL((three_interpolate_cl_pow2_kernel<4>), dim3(static_cast<unsigned>(gx * b)), dim3(256), 0, st, b, m, c,
+                           cv_shift, n, points, idx, weight, out);
+    } else if (c % 4 == 0 && al16)
         hipLaunchKernelGGL((three_interpolate_cl_kernel<4>), dim3(grid_for(nrows * (c / 4), block)), dim3(block), 0, st,
                            m, c, static_cast<long long>(n), nrows, points, idx, weight, out);
     else
