@@ -11,19 +11,21 @@
 // Design.  A brute-force scan is b*m*n pair tests (537 M at the headline shape) for a ball that holds a handful
 // of points.  One workgroup (1024 threads) owns QPW CONSECUTIVE queries of one cloud -- consecutive in the
 // query index, so every output of the workgroup (idx rows, grouped rows, counts) is one contiguous range.
-// Space is cut into cubic cells of width cs = 2.2 radius in a FIXED frame: cell(v) = (int)(v / cs) per axis (no
-// bounding box, no data-dependent grid: nothing to reduce before the first useful instruction).  A cell is
-// hashed to one of 65536 bits, h = (cx + A cy + B cz) mod 2^16.  The workgroup
-//   1  loads its queries and issues the loads of the whole cloud (16 points per thread stay in registers);
+// Space is cut into cubic cells of width cs = 2.2 radius in a FIXED frame: cell(v) = round(v / cs) per axis, read off
+// the mantissa of one fma (no bounding box, no data-dependent grid: nothing to reduce before the first useful
+// instruction).  A cell is hashed to one of 65536 bits: word = (cy + A cx + B cz) mod 2048, bit = cx mod 32
+// (8 VALU instructions per point: 3 fma, 2 mad_u24, 1 and, the LDS read, 1 bfe, 1 merge).  The workgroup
+//   1  loads its queries, clears the bitmap and the list heads, and requests the cloud (16 points per thread stay
+//      in registers);
 //   2  marks, in a 8 KB bitmap in LDS, the <= 8 cells that each query's padded box [q - rp, q + rp] touches
-//      (rp > radius; cs >= 2 rp, so <= 2 cells per axis; the 8 hashes of one query are distinct by the choice of
-//      A and B);
+//      (rp > radius; cs >= 2 rp, so <= 2 cells per axis);
 //   3  tests every point of the cloud against the bitmap (one 4-byte LDS read per point): a point whose bit is
 //      clear cannot be a hit of any of these queries (cell() is monotone, so a point inside a query's padded box
 //      computes one of that query's cells; hash collisions only add harmless candidates).  One LDS atomic per
-//      WAVE reserves slots for the survivors (a few hundred of 16384), which record their data index;
-//   4  one thread per survivor re-reads its coordinates (L2) and pushes it onto the list of its cell
-//      (4096 list heads, direct-mapped by the low hash bits);
+//      WAVE reserves slots for the survivors (a few hundred of 16384);
+//   4  the lanes that hold survivors re-read their coordinates (the register arrays cannot be indexed at run time;
+//      the latency hides behind the other waves' step 3) and push each onto the list of its cell (4096 list heads,
+//      direct-mapped by 12 hash bits);
 //   5  every query (G = 1024 / QPW lanes each, one lane per cell) walks the lists of its <= 8 cells, applies the
 //      reference's exact fp32 test, and keeps the nsample SMALLEST data indices in a sorted LDS row (= the first
 //      nsample hits of the reference's ascending scan);
@@ -47,9 +49,15 @@ namespace hf {
 
 constexpr int kCellSegPoints = 16384;   // points per register segment: NT threads hold 16384 / NT points each
 constexpr int kCellWords = 2048;        // bitmap words: 65536 hashed cells
-constexpr int kCellHeads = 4096;        // list heads, direct-mapped by the low 12 hash bits
-constexpr unsigned kCellHashA = 2437u;  // hash = cx + A cy + B cz: the 8 sums of subsets of {1, A, B} are distinct
-constexpr unsigned kCellHashB = 27163u; // mod 65536 and mod 4096, so one query's cells never share a bit or a list
+constexpr int kCellHeads = 4096;        // list heads, direct-mapped by 12 hash bits
+// key = 4 (cy + A cx + B cz) + (quarter-cell fraction of y): bits 2..12 = bitmap word, the bit in the word = cx mod 32
+// (x is a long axis of a LiDAR scene in the camera frame and in the sensor frame alike; A, B: fewest false candidates
+// on KITTI-sized scenes at radii 0.1 .. 2 in both frames, as good as a full 16-bit multiplicative hash).
+// List head = that word index | (cx & 1) << 11.  The 8 cells of a query never share a list: the two x sides differ
+// in cx & 1, and within one the word offsets {0, 1, B, B + 1} are distinct.
+constexpr unsigned kCellHashA = 97u;
+constexpr unsigned kCellHashB = 75u;
+constexpr unsigned kCellWordMask = (kCellWords - 1) << 2;   // byte offset of the bitmap word inside the key
 constexpr int kCellChunk = 2048;        // dense path: points per flush (<= cap)
 constexpr int kCellSlotBits = 12;       // row entry = (data index << 12) | slot in the LDS candidate buffer
 constexpr int kCellIdxBits = 19;        // candidate word = data index | (next slot + 1) << 19: n <= 2^19, cap < 2^12
@@ -75,6 +83,14 @@ __device__ __forceinline__ P3 load_p3(__amdgpu_buffer_rsrc_t r, unsigned elem)
     return P3{ __uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z) };
 }
 
+// LDS word at a byte offset from the start of the workgroup's allocation.  The kernel has no static LDS object, so
+// its dynamic region starts at 0 (cell_launch checks the attribute): the address needs no base added per access.
+constexpr unsigned kCellBitsOffset = 64;
+__device__ __forceinline__ unsigned lds_u32(unsigned byte_off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(static_cast<size_t>(byte_off));
+}
+
 // Diagnostic build only (-DHF_QBP_STAMPS, scripts/probes/qbp_stamps.py): wave 0 of every workgroup stamps the
 // shader clock at the phase boundaries into a buffer of its own.  The product library is built without it.
 #ifdef HF_QBP_STAMPS
@@ -88,8 +104,24 @@ __device__ unsigned long long g_qbp_stamps[4096 * 16];
         if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.y < 4096)                                          \
             g_qbp_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = ts_;                                     \
     } while (0)
+#define HF_STAMP_REAL(i, thr)                                                                                         \
+    do {                                                                                                              \
+        unsigned long long ts_;                                                                                       \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                               \
+        if (threadIdx.x == (thr) && blockIdx.x + gridDim.x * blockIdx.y < 4096)                                      \
+            g_qbp_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = ts_;                                     \
+    } while (0)
+#define HF_STAMP_LAST(i)                                                                                              \
+    do {                                                                                                              \
+        unsigned long long ts_;                                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                                   \
+        if (threadIdx.x == blockDim.x - 1 && blockIdx.x + gridDim.x * blockIdx.y < 4096)                             \
+            g_qbp_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = ts_;                                     \
+    } while (0)
 #else
 #define HF_STAMP(i) do { } while (0)
+#define HF_STAMP_LAST(i) do { } while (0)
+#define HF_STAMP_REAL(i, thr) do { } while (0)
 #endif
 
 // a * b + c on the low 24 bits of a and b: one full-rate instruction (hipcc turns __umul24 + add into the
@@ -151,6 +183,7 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     const float *p1 = xyz1 + static_cast<size_t>(bb) * n * 3;
     const float *p2 = xyz2 + (static_cast<size_t>(bb) * m + j0) * 3;
     if (stop == -1) return;
+    HF_STAMP_REAL(12, 0);
     HF_STAMP(0);
 
     // ---------------- 1: my query first (vmcnt retires in order), then the cloud ----------------
@@ -175,7 +208,11 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
             px[u] = p.x; py[u] = p.y; pz[u] = p.z;
         }
     };
-    load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kEarly>{}, 0);
+#ifndef HF_QBP_ORDER
+#define HF_QBP_ORDER 0
+#endif
+    if (HF_QBP_ORDER == 1) load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kCellPPT>{}, 0);
+    if (HF_QBP_ORDER == 3) load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kEarly>{}, 0);
     HF_STAMP(9);
     {
         typedef int i4 __attribute__((ext_vector_type(4)));
@@ -185,27 +222,40 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     }
     HF_STAMP(10);
     __syncthreads();
+    // the cloud requests go out behind the barrier: the query's latency is covered by issuing them
+    if (HF_QBP_ORDER == 0) load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kEarly>{}, 0);
     HF_STAMP(1);
 
     // cell of v along one axis = round(v / cs), read off the mantissa of fma(v, 1/cs, 1.5 * 2^23): one instruction,
     // monotone in v; exact while |v / cs| < 2^22 (queries beyond 2^21 cells switch to the exhaustive mode)
     auto cellc = [&](float v) -> unsigned { return __float_as_uint(__builtin_fmaf(v, inv_cs, 12582912.0f)); };
+    // the y axis in quarter cells (same trick, 4 / cs): its cell is the FLOOR of a quarter of that, the two fraction bits
+    // ride along in the low bits of the key where nothing reads them.  Exact while |v / cs| < 2^20.
+    const float inv_cs4 = 4.0f * inv_cs;
+    auto cellq = [&](float v) -> unsigned { return __float_as_uint(__builtin_fmaf(v, inv_cs4, 12582912.0f)); };
     // ---------------- 2: mark the cells my query's padded box touches ----------------
-    unsigned qhash = 0u;   // hash of the low-corner cell; bits 16..18: the box reaches into the next cell along x / y / z
+    // key of the low-corner cell (bits 0..12); bits 16..18: the box reaches into the next cell along x / y / z;
+    // bits 20..24: cx of the low corner mod 32
+    unsigned qhash = 0u;
+    auto corner_key = [&](int c) -> unsigned {
+        return qhash + 4u * ((c & 1) * kCellHashA + ((c >> 1) & 1) + ((c >> 2) & 1) * kCellHashB);
+    };
+    auto corner_cx = [&](int c) -> unsigned { return (qhash >> 20) + (c & 1); };   // low 5 bits
+    auto head_of = [&](unsigned key, unsigned cx) -> unsigned { return ((key & kCellWordMask) >> 2) | ((cx & 1u) << 11); };
     {
         // pad: > radius plus the fp32 rounding of q -/+ rp
         const float qmax = fmaxf(fabsf(qx), fmaxf(fabsf(qy), fabsf(qz)));
         const float rp = radius * 1.001f + 1e-6f * qmax;
-        const unsigned lx = cellc(qx - rp), ly = cellc(qy - rp), lz = cellc(qz - rp);
-        const unsigned hx = cellc(qx + rp) - lx, hy = cellc(qy + rp) - ly, hz = cellc(qz + rp) - lz;
+        const unsigned lx = cellc(qx - rp), ly = cellq(qy - rp) >> 2, lz = cellc(qz - rp);
+        const unsigned hx = cellc(qx + rp) - lx, hy = (cellq(qy + rp) >> 2) - ly, hz = cellc(qz + rp) - lz;
         // cs >= 2 rp with slack: 0 <= h <= 1.  Otherwise (coordinates ~1e5 radii away from the origin) -> exhaustive mode
-        if (qlive && (2.0f * rp * inv_cs > 0.995f || ((hx | hy | hz) & ~1u) || !(qmax * inv_cs < 2097152.0f))) sh.exh = 1;
-        qhash = mad_u24(lz, kCellHashB, mad_u24(ly, kCellHashA, lx)) & 0xffffu;
+        if (qlive && (2.0f * rp * inv_cs > 0.995f || ((hx | hy | hz) & ~1u) || !(qmax * inv_cs < 524288.0f))) sh.exh = 1;
+        qhash = mad_u24(lz, 4u * kCellHashB, mad_u24(lx, 4u * kCellHashA, ly << 2)) & kCellWordMask;
         qhash |= static_cast<unsigned>((hx & 1) | ((hy & 1) << 1) | ((hz & 1) << 2)) << 16;
+        qhash |= (lx & 31u) << 20;
         for (int c = sub; c < 8; c += G) {   // G >= 8: one cell per lane; G = 4: two
             if (qlive && (c & ~(qhash >> 16)) == 0) {
-                const unsigned h = (qhash + (c & 1) + ((c >> 1) & 1) * kCellHashA + ((c >> 2) & 1) * kCellHashB) & 0xffffu;
-                atomicOr(&bits[h >> 5], 1u << (h & 31));
+                atomicOr(&bits[(corner_key(c) & kCellWordMask) >> 2], 1u << (corner_cx(c) & 31u));
             }
         }
         if (qlive && sub == 0) qbuf[qi] = make_float4(qx, qy, qz, 0.f);
@@ -215,12 +265,14 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     HF_STAMP(3);
     if (stop == -2) return;
     const bool exh = sh.exh != 0;   // uniform
-    load_points(std::integral_constant<int, kEarly>{}, std::integral_constant<int, kCellPPT>{}, 0);
+    if (HF_QBP_ORDER == 0 || HF_QBP_ORDER == 3) load_points(std::integral_constant<int, kEarly>{}, std::integral_constant<int, kCellPPT>{}, 0);
+    if (HF_QBP_ORDER == 2) load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kCellPPT>{}, 0);
 
-    // hash of the cell of a point: the raw float bits go into the multiply-adds, only the low 16 bits of the result are
-    // used and those depend on the low 16 bits of the operands alone (the cell number modulo 2^16)
-    auto cell_hash = [&](float x, float y, float z) -> unsigned {
-        return mad_u24(cellc(z), kCellHashB, mad_u24(cellc(y), kCellHashA, cellc(x)));
+    // key of the cell of a point: the raw float bits go into the multiply-adds (24-bit operands; only bits 0..12 of the
+    // result are used and those depend on the low 13 bits of the operands alone); cx = raw bits of the x cell
+    auto point_key = [&](float x, float y, float z, unsigned &cx) -> unsigned {
+        cx = cellc(x);
+        return mad_u24(cellc(z), 4u * kCellHashB, mad_u24(cx, 4u * kCellHashA, cellq(y)));
     };
     // NP points per thread (k = k0 + u * 1024, valid below lim):
     //   pass 1  bitmap lookups, four in flight, -> one mask bit per point (no divergence);
@@ -231,18 +283,16 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
         unsigned mask = 0u;
 #pragma unroll
         for (int u0 = 0; u0 < NP; u0 += 4) {
-            unsigned h[4], w[4];
+            unsigned cx[4], w[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (u0 + i < NP) {
-                    h[i] = cell_hash(x[u0 + i], y[u0 + i], z[u0 + i]);
-                    w[i] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(bits) + ((h[i] >> 3) & (kCellWords * 4 - 4)));
-                }
+                if (u0 + i < NP) w[i] = lds_u32(kCellBitsOffset + (point_key(x[u0 + i], y[u0 + i], z[u0 + i], cx[i]) & kCellWordMask));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (u0 + i < NP) mask |= __builtin_amdgcn_ubfe(w[i], h[i], 1u) << (u0 + i);
+                if (u0 + i < NP) mask |= __builtin_amdgcn_ubfe(w[i], cx[i], 1u) << (u0 + i);
             __builtin_amdgcn_sched_barrier(0);   // finish a group before the next: the waits on the cloud loads stay incremental
         }
+        HF_STAMP(14);
         if (exh) mask = NP >= 32 ? ~0u : (1u << (NP & 31)) - 1u;
         // valid points: k0 + u * 1024 < lim
         const int nvalid = lim > k0 ? min(NP, (lim - k0 + kCellThreads - 1) / kCellThreads) : 0;
@@ -254,24 +304,38 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
         int base = 0;
         if (lane == 0) base = atomicAdd(&sh.nc, wtot);
         int slot = __builtin_amdgcn_readfirstlane(base) + inc - mine;
+        HF_STAMP(15);
+        // pass 2 (few lanes, few rounds): re-read the coordinates of up to four candidates at once -- the register
+        // arrays cannot be indexed by a run-time u -- and push each onto the list of its cell.  The latency of the
+        // re-reads hides behind the other waves' pass 1; no separate link step, no barrier for it.
         while (mask) {
-            const int u = __builtin_ctz(mask);
-            mask &= mask - 1u;
-            if (slot < cap) cand[slot].w = __int_as_float(k0 + u * kCellThreads);
-            ++slot;
+            int kk[4];
+            P3 pp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kk[i] = -1;
+                if (mask) {
+                    const int u = __builtin_ctz(mask);
+                    mask &= mask - 1u;
+                    kk[i] = k0 + u * kCellThreads;
+                    pp[i] = load_p3(rcloud, static_cast<unsigned>(kk[i]));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (kk[i] >= 0) {
+                    if (slot < cap) {
+                        unsigned cx;
+                        const unsigned key = point_key(pp[i].x, pp[i].y, pp[i].z, cx);
+                        const unsigned h = exh ? 0u : head_of(key, cx);
+                        const int old = atomicExch(&head[h], slot);
+                        cand[slot] = make_float4(pp[i].x, pp[i].y, pp[i].z, __int_as_float(kk[i] | ((old + 1) << kCellIdxBits)));
+                    }
+                    ++slot;
+                }
+            }
         }
     };
-    // after a barrier: one thread per candidate re-reads its coordinates and pushes it onto its cell's list
-    auto link_candidates = [&](int nc) {
-        for (int i = t; i < nc; i += kCellThreads) {
-            const int k = __float_as_int(cand[i].w);
-            const P3 p = load_p3(rcloud, static_cast<unsigned>(k));
-            const unsigned h = exh ? 0u : (cell_hash(p.x, p.y, p.z) & (kCellHeads - 1));
-            const int old = atomicExch(&head[h], i);
-            cand[i] = make_float4(p.x, p.y, p.z, __int_as_float(k | ((old + 1) << kCellIdxBits)));
-        }
-    };
-
     // block-wide AND (rare paths only; __syncthreads_and would add a static LDS object in front of the dynamic region)
     auto all_threads = [&](bool pred) -> bool {
         __syncthreads();
@@ -303,13 +367,13 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
         else if (G >= 8) {   // one cell per lane: no queue of lists
             cnext = 8;
             if (qlive && sub < 8 && (sub & ~(qhash >> 16)) == 0)
-                cur = head[(qhash + (sub & 1) + ((sub >> 1) & 1) * kCellHashA + ((sub >> 2) & 1) * kCellHashB) & (kCellHeads - 1)];
+                cur = head[head_of(corner_key(sub), corner_cx(sub))];
         }
     };
     auto next_list = [&](int &cur, int &cnext) {
         while (cur < 0 && cnext < 8) {
             if (qlive && (cnext & ~(qhash >> 16)) == 0)
-                cur = head[(qhash + (cnext & 1) + ((cnext >> 1) & 1) * kCellHashA + ((cnext >> 2) & 1) * kCellHashB) & (kCellHeads - 1)];
+                cur = head[head_of(corner_key(cnext), corner_cx(cnext))];
             cnext += G;
         }
     };
@@ -413,8 +477,6 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
         if (nc <= cap) {
             // common case: every candidate of the segment fits -> one search
             if (nc > 0) {
-                link_candidates(nc);
-                __syncthreads();
                 HF_STAMP(6);
                 if (stop == 2) return;
                 search();
@@ -438,8 +500,6 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
                 }
                 __syncthreads();
                 add_points(std::integral_constant<int, kCellChunkSlots>{}, cx, cy, cz, base + t, segend);
-                __syncthreads();
-                link_candidates(sh.nc);
                 __syncthreads();
                 search();
                 nflush += 2;   // rows may refer to overwritten slots: step 6 reads the cloud
@@ -499,6 +559,8 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
         }
     }
     HF_STAMP(8);
+    HF_STAMP_LAST(11);
+    HF_STAMP_REAL(13, blockDim.x - 1);
 }
 
 static size_t cell_lds_bytes(int nsample, int qpw, int cap, int nt)
@@ -515,11 +577,18 @@ static int cell_env_int(const char *name, int dflt)
 }
 
 template <bool GRP, int SM, int NT>
-static void cell_launch(dim3 grid, size_t lds, hipStream_t st, int n, int m, int qpw, int glog, float radius, float thresh,
+static int cell_launch(dim3 grid, size_t lds, hipStream_t st, int n, int m, int qpw, int glog, float radius, float thresh,
                         float inv_cs, int nsample, int ns_shift, int cap, int stop, const float *xyz1, const float *xyz2,
                         int center, int *idx, int *pts_cnt, float *grouped)
 {
     static size_t lds_allowed = 0;   // raise the dynamic-LDS limit of this instantiation once, not on every launch
+    static int static_lds = -1;
+    if (static_lds < 0) {
+        hipFuncAttributes fa;
+        static_lds = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&qbp_cell_kernel<GRP, SM, NT>)) == hipSuccess
+                         ? static_cast<int>(fa.sharedSizeBytes) : 1;
+    }
+    if (static_lds != 0) return HF_EINVAL;   // lds_u32 assumes the dynamic region starts at LDS address 0
     if (lds > lds_allowed) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_cell_kernel<GRP, SM, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
@@ -527,6 +596,7 @@ static void cell_launch(dim3 grid, size_t lds, hipStream_t st, int n, int m, int
     }
     hipLaunchKernelGGL((qbp_cell_kernel<GRP, SM, NT>), grid, dim3(NT), lds, st, n, m, qpw, glog, radius, thresh, inv_cs,
                        nsample, ns_shift, cap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped);
+    return launch_status();
 }
 
 // returns HF_EINVAL when the shape is outside the cell kernel's range (the caller then takes an older kernel)
@@ -557,8 +627,8 @@ int launch_ball_query_cell(int b, int n, int m, float radius, float thresh, int 
 #define HF_CELL_ARGS grid, lds, st, n, m, qpw, glog, radius, thresh, inv_cs, nsample, ns_shift, cap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped
 #define HF_CELL_DISPATCH(GRP, SMODE)                                                                                   \
     do {                                                                                                              \
-        if (nt == 1024) cell_launch<GRP, SMODE, 1024>(HF_CELL_ARGS);                                                  \
-        else cell_launch<GRP, SMODE, 512>(HF_CELL_ARGS);                                                              \
+        if (nt == 1024) return cell_launch<GRP, SMODE, 1024>(HF_CELL_ARGS);                                           \
+        else return cell_launch<GRP, SMODE, 512>(HF_CELL_ARGS);                                                       \
     } while (0)
     if (grouped) {
         if (sm == 0) HF_CELL_DISPATCH(true, 0);
@@ -571,7 +641,6 @@ int launch_ball_query_cell(int b, int n, int m, float radius, float thresh, int 
     }
 #undef HF_CELL_DISPATCH
 #undef HF_CELL_ARGS
-    return launch_status();
 }
 
 }  // namespace hf

@@ -1,6 +1,6 @@
 // Probe: how fast can every CU read the same 196 KB cloud (8 clouds, 32 workgroups each) from its XCD's L2?
 // Variants: 0 = dwordx3 per lane (AoS points, 12-byte stride), 1 = dwordx4 per lane (flat stream), 2 = 3 x dword per lane,
-// 3 = dwordx4 via buffer_load ... lds (LDS-DMA).  Build: hipcc --offload-arch=gfx950 -O3 l2_read_probe.hip -o l2_read_probe
+// 4 = three aligned dwordx4 per lane at a 48-byte lane stride (four points).  Build: hipcc --offload-arch=gfx950 -O3 l2_read_probe.hip -o l2_read_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
@@ -31,6 +31,19 @@ __global__ __launch_bounds__(NT) void probe(const float *__restrict__ xyz, int n
         for (int u = 0; u < PPT * 3; ++u) x[u] = p[u * NT + t];
 #pragma unroll
         for (int u = 0; u < PPT * 3; ++u) acc += x[u];
+    }
+    if (V == 4) {
+        // four consecutive points per lane = three aligned float4 at a 48-byte lane stride
+        constexpr int Q = PPT / 4;
+        float4 v[Q][3];
+#pragma unroll
+        for (int u = 0; u < Q; ++u)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[u][i] = *(const float4 *)(p + (size_t)(u * NT + t) * 12 + 4 * i);
+#pragma unroll
+        for (int u = 0; u < Q; ++u)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc += v[u][i].x + v[u][i].y * v[u][i].z + v[u][i].w;
     }
     if (acc == 123.456f) out[blockIdx.x * NT + t] = acc;
 }
@@ -71,6 +84,7 @@ int main()
     printf("empty  256 thr, 0 LDS      %.2f us\n", run_empty<256>(o, 200, 0));
     printf("dwordx3 1024 thr  %.2f us\n", run<0, 1024>(d, o, 200));
     printf("dwordx4 1024 thr  %.2f us\n", run<1, 1024>(d, o, 200));
+    printf("3x dwordx4 @48B 1024 thr  %.2f us\n", run<4, 1024>(d, o, 200));
     printf("dword   1024 thr  %.2f us\n", run<2, 1024>(d, o, 200));
     printf("dwordx3  512 thr  %.2f us\n", run<0, 512>(d, o, 200));
     printf("dwordx4  512 thr  %.2f us\n", run<1, 512>(d, o, 200));

@@ -34,4 +34,13 @@ for i, nm in enumerate(names[1:]):
     print("%-27s %8.0f %8.0f %8.0f" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
 print("inside the first phase: start -> loads issued %.0f, -> LDS initialised %.0f, -> barrier0 passed %.0f" % (
     np.median(a[:, 9] - a[:, 0]), np.median(a[:, 10] - a[:, 9]), np.median(a[:, 1] - a[:, 10])))
+print("inside pass1+2: barrierA -> masks done %.0f, -> slots reserved %.0f, -> candidates re-read and linked %.0f" % (
+    np.median(a[:, 14] - a[:, 3]), np.median(a[:, 15] - a[:, 14]), np.median(a[:, 4] - a[:, 15])))
 print("total                       %8.0f" % np.median(a[:, NS - 1] - a[:, 0]))
+# dispatch skew and tail on the constant 100 MHz clock (s_memrealtime, the same for the whole device; 10 ns ticks)
+t0 = a[:, 12].min()
+st = (a[:, 12] - t0) * 10
+en = (a[:, 13] - t0) * 10
+print("workgroup start after the first one, ns: median %d  p90 %d  max %d" % (np.median(st), np.percentile(st, 90), st.max()))
+print("last wave of a workgroup ends, ns:      min %d  median %d  p90 %d  max %d" % (en.min(), np.median(en), np.percentile(en, 90), en.max()))
+print("workgroup lifetime, ns:                 median %d  p10 %d  p90 %d" % (np.median(en - st), np.percentile(en - st, 10), np.percentile(en - st, 90)))
