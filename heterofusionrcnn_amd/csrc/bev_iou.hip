@@ -355,15 +355,33 @@ __global__ __launch_bounds__(kTileThreads, 4) void bev_iou_kernel(int num_a, con
 // iou(row, col*64+j) > thresh, j > row inside the diagonal tile (bev_iou_g.cu:256-298).
 constexpr int kNmsThreads = kTileThreads;
 
+// An entry of a column block's list: a nonzero mask word right of the diagonal and the row it belongs to.
+struct __attribute__((aligned(16))) NmsEntry {
+    unsigned long long word;
+    int row, pad;
+};
+constexpr int kNmsListCap = 2048;   // entries per column block (a column that overflows is swept from the dense mask)
+
+// per-frame workspace of hf_oriented_nms:
+// [mask n*cb words][counts cb ints, padded][lists cb * kNmsListCap entries][transposed diagonal words, n]
+__host__ __device__ inline size_t nms_ws_counts_offset(int n) { return (sizeof(unsigned long long) * static_cast<size_t>(n) * ((n + 63) / 64) + 255) & ~static_cast<size_t>(255); }
+__host__ __device__ inline size_t nms_ws_lists_offset(int n) { return nms_ws_counts_offset(n) + ((sizeof(int) * static_cast<size_t>((n + 63) / 64) + 255) & ~static_cast<size_t>(255)); }
+__host__ __device__ inline size_t nms_ws_diagt_offset(int n) { return nms_ws_lists_offset(n) + sizeof(NmsEntry) * static_cast<size_t>((n + 63) / 64) * kNmsListCap; }
+__host__ __device__ inline size_t nms_ws_bytes(int n) { return nms_ws_diagt_offset(n) + ((sizeof(unsigned long long) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255)); }
+
+// UPPER_ONLY = the form hf_oriented_nms launches: `mask` is the frame-0 workspace (stride ws_stride bytes per frame),
+// tiles below the diagonal are skipped, and every nonzero word right of the diagonal is also appended to the list of
+// its column block.
 template <bool UPPER_ONLY>
 __global__ __launch_bounds__(kNmsThreads, 4) void nms_mask_kernel(int n, float thresh, const float *__restrict__ boxes,
-                                                               unsigned long long *__restrict__ mask)
+                                                               unsigned long long *__restrict__ mask, size_t ws_stride)
 {
     const int row_t = blockIdx.y, col_t = blockIdx.x;
     if (UPPER_ONLY && col_t < row_t) return;  // never read by the sweep (bev_iou.cpp:100-103 starts at nblock)
-    // blockIdx.z = frame of a batched call: every frame has its own (n,5) boxes and (n, ceil(n/64)) mask
+    // blockIdx.z = frame of a batched call: every frame has its own (n,5) boxes and workspace / (n, ceil(n/64)) mask
     boxes += static_cast<size_t>(blockIdx.z) * n * 5;
-    mask += static_cast<size_t>(blockIdx.z) * n * ((n + 63) / 64);
+    unsigned char *ws = reinterpret_cast<unsigned char *>(mask) + static_cast<size_t>(blockIdx.z) * ws_stride;
+    mask = reinterpret_cast<unsigned long long *>(ws);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TileShared &sh = *reinterpret_cast<TileShared *>(smem_raw);
     const int t = threadIdx.x;
@@ -396,102 +414,150 @@ __global__ __launch_bounds__(kNmsThreads, 4) void nms_mask_kernel(int n, float t
     }
     __syncthreads();
     const int col_blocks = (n + 63) / 64;
-    if (t < row_size) mask[(static_cast<size_t>(row_t) * 64 + t) * col_blocks + col_t] = sh.words[t];
+    if (t < row_size) {
+        const unsigned long long w = sh.words[t];
+        mask[(static_cast<size_t>(row_t) * 64 + t) * col_blocks + col_t] = w;
+        if (UPPER_ONLY && col_t > row_t && w != 0ull) {
+            int *counts = reinterpret_cast<int *>(ws + nms_ws_counts_offset(n));
+            NmsEntry *lists = reinterpret_cast<NmsEntry *>(ws + nms_ws_lists_offset(n));
+            const int slot = atomicAdd(&counts[col_t], 1);
+            if (slot < kNmsListCap) lists[static_cast<size_t>(col_t) * kNmsListCap + slot] = NmsEntry{ w, row_t * 64 + t, 0 };
+        }
+    }
+    if (UPPER_ONLY && col_t == row_t && t < col_size) {
+        // the diagonal tile, transposed: bit r of word c = box row_t*64+r suppresses box row_t*64+c ("who kills me"),
+        // the form the sweep resolves a block with
+        unsigned long long tw = 0ull;
+        for (int r = 0; r < 64; ++r) tw |= ((sh.words[r] >> t) & 1ull) << r;
+        reinterpret_cast<unsigned long long *>(ws + nms_ws_diagt_offset(n))[row_t * 64 + t] = tw;
+    }
 }
 
 // ---------------------------------------------------------------- greedy sweep on the device
-// bev_iou.cpp:87-112 without the host.  One 1024-thread workgroup per frame walks the column blocks in order, the
-// removal words remv[col block] live in LDS.  Per block of 64 boxes:
-//   resolve  wave 0: lane l holds the diagonal word of box blk*64+l; a scalar loop visits only the boxes that are still
-//            alive (find-first-set on the alive mask), keeps each and ORs its diagonal word into the alive mask's
-//            complement -- the host loop's `if (!(remv[nblock] & 1 << inblock))`;
-//   push     all threads: every kept box of the block ORs its mask row, words blk+1 .. cb-1, into remv[] (the host
-//            loop's `remv[j] |= p[j]`): thread -> (one of four row groups, word), rows are read with coalesced 8-byte
-//            loads, combined in registers and merged with one LDS atomic per thread and word.
-// (The round-1 form PULLED instead: for every block it re-read one word of every box kept so far, 8-byte reads at a
-// 1 KB stride -- 0.95 ms of the 1.14 ms at 9000 boxes.)
+// bev_iou.cpp:87-112 without the host.  One 1024-thread workgroup per frame walks the column blocks in order; the kept
+// bits of every block live in LDS.  The dense mask is 8 n^2/64 bytes (10 MB at 9000 boxes) of which almost every word is
+// zero, and ONE compute unit cannot stream it (measured: ~17 GB/s -> 0.25 ms for the upper triangle however deep the
+// prefetch).  So the mask kernel also files every nonzero word right of the diagonal under its column block, and
+// step blk reads that short list:
+//   gather   waves 1..15: the entries of column block blk (requested kSweepLead steps earlier, they depend on no
+//            decision): an entry whose row was kept adds its word to the block's removal word (an LDS atomic) -- the
+//            host loop's `remv[j] |= p[j]`, transposed;
+//   resolve  wave 0: lane l holds the TRANSPOSED diagonal word of box blk*64+l (which boxes of the block suppress it; the
+//            mask kernel writes it next to the mask).  kept = alive and no kept suppressor: iterated for the whole wave
+//            at once until nothing changes (one ballot per round, a round per link of the longest suppression chain)
+//            -- the host loop's `if (!(remv[nblock] & 1 << inblock))` without its 64 dependent steps.
+// A column block whose list overflowed (> kNmsListCap nonzero words: thousands of boxes overlapping the same 64) is
+// gathered from the dense mask instead: every kept row so far is asked for its word of that column.
+// (Round 1 PULLED like that for every block: 0.95 ms of 1.14 ms.  Pushing kept rows into all later words, even with the
+// loads issued four steps ahead of the decision, stayed at 0.25 ms: the single CU's memory parallelism.)
 constexpr int kSweepThreads = 1024;
+constexpr int kSweepGatherers = kSweepThreads - 64;
+constexpr int kSweepLead = 4;   // steps between the request of a column's first entries and their use
 
-__global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, const unsigned long long *__restrict__ mask,
-                                                                  int *__restrict__ keep, int *__restrict__ num_kept)
+__global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, int chunk_blocks, const unsigned char *__restrict__ ws_base,
+                                                                  size_t ws_stride, int *__restrict__ keep,
+                                                                  int *__restrict__ num_kept)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long *remv = reinterpret_cast<unsigned long long *>(smem_raw);   // cb words
-    // blockIdx.x = frame of a batched call
     const int cb = (n + 63) / 64;
-    mask += static_cast<size_t>(blockIdx.x) * n * cb;
+    // blockIdx.x = frame of a batched call
+    const unsigned char *ws = ws_base + static_cast<size_t>(blockIdx.x) * ws_stride;
+    const unsigned long long *mask = reinterpret_cast<const unsigned long long *>(ws);
+    const int *counts = reinterpret_cast<const int *>(ws + nms_ws_counts_offset(n));
+    const NmsEntry *lists = reinterpret_cast<const NmsEntry *>(ws + nms_ws_lists_offset(n));
     keep += static_cast<size_t>(blockIdx.x) * n;
     if (num_kept) num_kept += blockIdx.x;
-    __shared__ unsigned long long kept_bits[2];
+    unsigned long long *diagw = reinterpret_cast<unsigned long long *>(smem_raw);   // chunk_blocks * 64: diagonal words
+    unsigned long long *keptw = diagw + chunk_blocks * 64;                          // cb: kept bits per block
+    unsigned long long *remv = keptw + cb;                                          // cb: removal word per block
+    int *cnts = reinterpret_cast<int *>(remv + cb);                                 // cb: entries filed under the block
     __shared__ int kept_total;
-    __shared__ int klist[2][64];   // the kept boxes of a block (lane numbers), in order; double-buffered by block parity
     const int t = threadIdx.x;
-    for (int w = t; w < cb; w += kSweepThreads) remv[w] = 0ull;
-    if (t == 0) { kept_total = 0; kept_bits[0] = 0ull; kept_bits[1] = 0ull; }
+    for (int w = t; w < cb; w += kSweepThreads) { remv[w] = 0ull; keptw[w] = 0ull; cnts[w] = counts[w]; }
+    if (t == 0) kept_total = 0;
+    // every chunk_blocks steps all threads load the (transposed) diagonal words of the next chunk: wave 0 never waits
+    // for memory
+    const unsigned long long *diagt = reinterpret_cast<const unsigned long long *>(ws + nms_ws_diagt_offset(n));
+    auto load_chunk = [&](int c0) {
+        const int i0 = c0 * 64, i1 = min(n, (c0 + chunk_blocks) * 64);
+        for (int i = i0 + t; i < i1; i += kSweepThreads) diagw[i - i0] = diagt[i];
+    };
     __syncthreads();
-    // Step blk: wave 0 resolves block blk while waves 1..15 push the rows kept in block blk-1 into words blk+1.. .
-    // Word blk of those rows -- the one wave 0 needs right now -- is fetched by wave 0 itself.
-    // wave 0 keeps two words per lane one step ahead of their use (they do not depend on any decision): the diagonal
-    // word of its box in the next block and word blk+1 of its box in the current block
-    unsigned long long diag = 0ull, prevw = 0ull;
-    if (t < 64) diag = t < n ? mask[static_cast<size_t>(t) * cb] : 0ull;
-    for (int blk = 0; blk <= cb; ++blk) {
-        const int par = blk & 1;
-        if (t < 64) {
-            if (blk < cb) {
-                unsigned long long diag_n = 0ull, prevw_n = 0ull;
-                if (blk + 1 < cb) {
-                    const int in = (blk + 1) * 64 + t, ic = blk * 64 + t;
-                    diag_n = in < n ? mask[static_cast<size_t>(in) * cb + blk + 1] : 0ull;
-                    prevw_n = ic < n ? mask[static_cast<size_t>(ic) * cb + blk + 1] : 0ull;
-                }
-                const unsigned long long kprev = blk > 0 ? kept_bits[par ^ 1] : 0ull;
-                if ((kprev >> t) & 1ull) atomicOr(&remv[blk], prevw);
-                const int i = blk * 64 + t;
-                const int lim = min(64, n - blk * 64);
-                const unsigned long long valid = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                asm volatile("" ::: "memory");
-                unsigned long long dead = remv[blk];   // suppressed by boxes kept in earlier blocks
-                unsigned long long kb = 0ull;
-                unsigned long long alive = ~dead & valid;
-                while (alive) {   // wave-uniform scalar loop over the boxes that survive
-                    const int l = __builtin_ctzll(alive);
-                    kb |= 1ull << l;
-                    const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(diag & 0xffffffffu), l);
-                    const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(diag >> 32), l);
-                    dead |= (static_cast<unsigned long long>(hi) << 32) | lo;   // bits <= l of a diagonal word are never set
-                    alive = ~dead & valid & ~((2ull << l) - 1ull);
-                }
-                const int before = kept_total;
-                if ((kb >> t) & 1ull) {
-                    const int o = __builtin_popcountll(kb & ((1ull << t) - 1ull));
-                    keep[before + o] = i;
-                    klist[par][o] = t;
-                }
-                if (t == 0) { kept_total = before + __builtin_popcountll(kb); kept_bits[par] = kb; }
-                diag = diag_n;
-                prevw = prevw_n;
+    // Two loops with the same barriers: the resolving wave and the gatherers share nothing but LDS.
+    if (t < 64) {
+        __builtin_amdgcn_s_setprio(3);
+        for (int blk = 0; blk < cb; ++blk) {
+            if (blk % chunk_blocks == 0) {
+                load_chunk(blk);
+                __syncthreads();
             }
-        } else if (blk > 0) {
-            // rows kept in block blk-1 -> words blk+1 .. cb-1; thread -> (row group g of 4, word w): consecutive threads
-            // read consecutive words of a row (coalesced); group g takes the kept boxes number g, g+4, ...
-            const unsigned long long kb = kept_bits[par ^ 1];
-            const int nw = cb - blk - 1;
-            if (kb != 0ull && nw > 0) {
-                const int u = t - 64;
-                const int g = u / 240;
-                const int nk = __builtin_popcountll(kb);
-                const int *kl = klist[par ^ 1];
-                for (int w = u - g * 240; w < nw; w += 240) {
-                    unsigned long long acc = 0ull;
-                    for (int o = g; o < nk; o += 4)
-                        acc |= mask[static_cast<size_t>((blk - 1) * 64 + kl[o]) * cb + blk + 1 + w];
-                    if (acc) atomicOr(&remv[blk + 1 + w], acc);
-                }
+            __syncthreads();   // the gatherers are done with column blk
+            const int i = blk * 64 + t;
+            const int lim = min(64, n - blk * 64);
+            const unsigned long long valid = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
+            // who (of this block) suppresses my box if kept: bits below my lane only
+            const unsigned long long killers = t < lim ? diagw[(blk % chunk_blocks) * 64 + t] : 0ull;
+            const unsigned long long alive = ~remv[blk] & valid;   // not suppressed by boxes kept in earlier blocks
+            // kept[l] = alive[l] and no kept killer: its unique solution is the fixed point of the whole-wave update below
+            // (position l is final after l+1 rounds; a chain of suppressions is rarely deeper than a few boxes)
+            unsigned long long kb = alive;
+            for (;;) {
+                const unsigned long long next = alive & ~__ballot((killers & kb) != 0ull);
+                if (next == kb) break;   // wave-uniform
+                kb = next;
             }
+            const int before = kept_total;
+            if ((kb >> t) & 1ull) keep[before + __builtin_popcountll(kb & ((1ull << t) - 1ull))] = i;
+            if (t == 0) { kept_total = before + __builtin_popcountll(kb); keptw[blk] = kb; }
+            __syncthreads();   // block blk is decided
         }
-        __syncthreads();
+    } else {
+        const int u = t - 64;
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        // the first entry of a column for this thread, requested kSweepLead steps ahead through a range-checked buffer
+        // load (a column with fewer entries, or past the last one, returns zeros: row 0 / word 0 adds nothing)
+        auto request = [&](int col) -> u4v {
+            const bool live = col < cb;   // uniform
+            const int cnt = live ? min(cnts[col], kNmsListCap) : 0;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<NmsEntry *>(lists + static_cast<size_t>(live ? col : 0) * kNmsListCap), 0, cnt * 16, 0x00020000);
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, u * 16, 0, 0);
+        };
+        auto kept_row = [&](int row) -> bool { return (keptw[row >> 6] >> (row & 63)) & 1ull; };
+        u4v e0 = request(1), e1 = request(2), e2 = request(3), e3 = request(4);   // column 0 has no rows before it
+        static_assert(kSweepLead == 4, "four entry registers rotate below");
+        auto gstep = [&](int blk, u4v &e) {
+            if (blk % chunk_blocks == 0) {
+                load_chunk(blk);
+                __syncthreads();
+            }
+            if (blk > 0) {
+                const int cnt = cnts[blk];   // uniform
+                unsigned long long acc = 0ull;
+                if (cnt <= kNmsListCap) {
+                    const unsigned long long w0 = (static_cast<unsigned long long>(e.y) << 32) | e.x;
+                    if (w0 != 0ull && kept_row(static_cast<int>(e.z))) acc = w0;
+                    for (int k = u + kSweepGatherers; k < cnt; k += kSweepGatherers) {   // long lists: the rest, on demand
+                        const NmsEntry x = lists[static_cast<size_t>(blk) * kNmsListCap + k];
+                        if (kept_row(x.row)) acc |= x.word;
+                    }
+                } else {
+                    // overflow: the dense mask, one word per kept row before this block
+                    for (int i = u; i < blk * 64; i += kSweepGatherers)
+                        if (kept_row(i)) acc |= mask[static_cast<size_t>(i) * cb + blk];
+                }
+                if (acc != 0ull) atomicOr(&remv[blk], acc);   // few lanes hold anything: cheaper than a wave reduction first
+            }
+            e = request(blk + kSweepLead);
+            __syncthreads();   // column blk gathered
+            __syncthreads();   // block blk decided
+        };
+        for (int base = 0; base < cb; base += 4) {
+            gstep(base, e3);
+            if (base + 1 < cb) gstep(base + 1, e0);
+            if (base + 2 < cb) gstep(base + 2, e1);
+            if (base + 3 < cb) gstep(base + 3, e2);
+        }
     }
     const int kept = kept_total;
     // pad with keep[0]; box 0 is always kept (nothing precedes it), bev_iou.cpp:110-112
@@ -552,15 +618,14 @@ HF_API int hf_nms_mask(const float *boxes, unsigned long long *mask, int boxes_n
     if (cb > 65535) return HF_EINVAL;
     tile_lds_attr(&nms_mask_kernel<false>);
     hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(cb, cb), dim3(kNmsThreads), sizeof(TileShared), as_stream(stream), boxes_num,
-                       nms_overlap_thresh, boxes, mask);
+                       nms_overlap_thresh, boxes, mask, static_cast<size_t>(0));
     return launch_status();
 }
 
 HF_API size_t hf_oriented_nms_workspace(int n)
 {
     if (n <= 0) return 0;
-    const size_t cb = (static_cast<size_t>(n) + 63) / 64;
-    return sizeof(unsigned long long) * static_cast<size_t>(n) * cb;
+    return nms_ws_bytes(n);   // dense mask + per-column-block counts + per-column-block lists of nonzero words
 }
 
 HF_API int hf_oriented_nms(const float *boxes, int n, float thresh, int *keep, int *num_kept, void *workspace,
@@ -576,17 +641,29 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
     if (frames <= 0 || frames > 65535 || n <= 0 || !(thresh >= 0.0f) || !boxes || !keep) return HF_EINVAL;
     if (!workspace || workspace_bytes < static_cast<size_t>(frames) * hf_oriented_nms_workspace(n)) return HF_EWORKSPACE;
     const int cb = (n + 63) / 64;
-    const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(cb);  // removal words
-    if (cb > 16384) return HF_EINVAL;     // n <= ~1 000 000 boxes (pre_nms_size is 9000)
+    // LDS: kept bits + removal words per block, and the diagonal words of a chunk of blocks (all of them up to 8192 boxes)
+    const int chunk_blocks = std::min(cb, 128);
+    const size_t lds = sizeof(unsigned long long) * (2 * static_cast<size_t>(cb) + 64 * static_cast<size_t>(chunk_blocks)) + sizeof(int) * static_cast<size_t>(cb);
+    if (cb > 8192 || lds > 160 * 1024 - 256) return HF_EINVAL;   // n <= 524 288 boxes (pre_nms_size is 9000)
     hipStream_t st = as_stream(stream);
-    unsigned long long *mask = static_cast<unsigned long long *>(workspace);
-    tile_lds_attr(&nms_mask_kernel<true>);
-    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(cb, cb, frames), dim3(kNmsThreads), sizeof(TileShared), st, n, thresh, boxes, mask);
-    int rc = launch_status();
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    const size_t ws_stride = nms_ws_bytes(n);
+    // the list counters start at zero (one strided memset: they sit at the same offset of every frame's workspace)
+    int rc = hip_status(hipMemset2DAsync(ws + nms_ws_counts_offset(n), ws_stride, 0, sizeof(int) * static_cast<size_t>(cb), frames, st));
     if (rc != HF_OK) return rc;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_sweep_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(frames), dim3(kSweepThreads), lds, st, n, mask, keep, num_kept);
+    tile_lds_attr(&nms_mask_kernel<true>);
+    hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(cb, cb, frames), dim3(kNmsThreads), sizeof(TileShared), st, n, thresh, boxes,
+                       reinterpret_cast<unsigned long long *>(ws), ws_stride);
+    rc = launch_status();
+    if (rc != HF_OK) return rc;
+    const char *nms_stop = getenv("HF_NMS_STOP");   // diagnostics only: 1 = mask kernel alone (keep[] is not written)
+    if (nms_stop && nms_stop[0] == '1') return HF_OK;
+    static size_t sweep_lds_allowed = 48 * 1024;   // raise the dynamic-LDS limit once, not on every launch
+    if (lds > sweep_lds_allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256);
+        sweep_lds_allowed = 160 * 1024 - 256;
+    }
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(frames), dim3(kSweepThreads), lds, st, n, chunk_blocks, ws, ws_stride, keep, num_kept);
     return launch_status();
 }

@@ -8,7 +8,24 @@ from bench import rand_bev, time_op
 rng = np.random.default_rng(3)
 a = torch.from_numpy(rand_bev(rng, 70000)).cuda()
 g = torch.from_numpy(rand_bev(rng, 64)).cuda()
-res = {"bev_iou_70000x64_us": round(time_op(lambda: hf.compute_bev_iou(a, g), iters=50), 2)}
+from heterofusionrcnn_amd import _lib
+L = _lib.lib()
+def burst_bev(na, launches=200):
+    """direct C-ABI launches, outputs preallocated: kernel + launch gap (the Python wrapper costs more than the kernel)"""
+    aa = a[:na].contiguous()
+    ov = torch.empty((na, 64), dtype=torch.float32, device="cuda"); io = torch.empty_like(ov)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (na, aa.data_ptr(), 64, g.data_ptr(), ov.data_ptr(), io.data_ptr(), st)
+    for _ in range(10):
+        assert L.hf_compute_bev_iou(*args) == 0
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        L.hf_compute_bev_iou(*args)
+    e1.record(); torch.cuda.synchronize()
+    return round(1e3 * e0.elapsed_time(e1) / launches, 2)
+res = {"bev_iou_70000x64_us": burst_bev(70000), "bev_iou_65536x64_us": burst_bev(65536), "bev_iou_32768x64_us": burst_bev(32768)}
 res["bev_iou_Gboxpairs_per_s"] = round(70000 * 64 / res["bev_iou_70000x64_us"] / 1e3, 1)
 for seed, thresh in ((4, 0.8), (4, 0.01)):
     r2 = np.random.default_rng(seed)
@@ -21,6 +38,19 @@ for seed, thresh in ((4, 0.8), (4, 0.01)):
     res["oriented_nms_9000_clustered_t%.2f_us" % thresh] = round(time_op(lambda: hf.oriented_nms(nb, thresh), iters=10, warm=2), 1)
 nb = torch.from_numpy(rand_bev(rng, 9000)).cuda()
 res["oriented_nms_9000_uniform_t0.80_us"] = round(time_op(lambda: hf.oriented_nms(nb, 0.8), iters=10, warm=2), 1)
+import time
+def wall(fn, iters=20):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return round(1e6 * (time.perf_counter() - t0) / iters, 1)
+res["oriented_nms_9000_uniform_t0.80_wallclock_us"] = wall(lambda: hf.oriented_nms(nb, 0.8))
+os.environ["HF_NMS_STOP"] = "1"
+res["nms_mask_alone_uniform_us"] = wall(lambda: hf.oriented_nms(nb, 0.8))
+nbc = torch.from_numpy(boxes.astype(np.float32)).cuda()
+res["nms_mask_alone_clustered_us"] = wall(lambda: hf.oriented_nms(nbc, 0.01))
+os.environ.pop("HF_NMS_STOP")
 print(json.dumps(res, indent=1))
 if os.environ.get("PHASES"):
     for stop in (1, 2, 3, 4, 0):
