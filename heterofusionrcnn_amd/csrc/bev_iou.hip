@@ -79,11 +79,13 @@ __device__ __forceinline__ Pt rot_center(Pt c, float ac, float as, Pt p)
 
 // Everything about one box that does not depend on its partner: evaluated once per box per tile
 // (the reference recomputes cos/sin and the rotated corners for every pair, bev_iou_g.cu:130-140).
-struct BoxPre {
+struct __attribute__((aligned(16))) BoxPre {
+    float cx, cy, rad, mag; // centre, a bound on the circumradius (half perimeter), |cx| + |cy| + rad: the first filter
+                            // reads these four with one 16-byte LDS access
     Pt cor[4];              // rotated corners, order of bev_iou_g.cu:118-128
     float cs, sn;           // cos(angle), sin(angle)
     float box[5];           // x1, y1, x2, y2, angle
-    float cx, cy, rad;      // centre and a bound on the circumradius (half perimeter), for the first filter
+    float pad_;
 };
 
 __device__ __forceinline__ void box_precompute(const float *b, BoxPre &o)
@@ -100,6 +102,7 @@ __device__ __forceinline__ void box_precompute(const float *b, BoxPre &o)
     o.cx = c.x;
     o.cy = c.y;
     o.rad = (fabsf(b[2] - b[0]) + fabsf(b[3] - b[1])) * 0.5f;
+    o.mag = fabsf(o.cx) + fabsf(o.cy) + o.rad;
 }
 
 // first filter, 6 LDS words per pair: centres further apart than the two radius bounds plus a slack that
@@ -107,7 +110,7 @@ __device__ __forceinline__ void box_precompute(const float *b, BoxPre &o)
 // corner inside: bev_iou_g.cu:150-176 leave cnt = 0).
 __device__ __forceinline__ bool circles_apart(const BoxPre &a, const BoxPre &b)
 {
-    const float mag = fabsf(a.cx) + fabsf(a.cy) + fabsf(b.cx) + fabsf(b.cy) + a.rad + b.rad;
+    const float mag = a.mag + b.mag;
     const float reach = a.rad + b.rad + 1e-3f + 1e-5f * mag;
     const float dx = a.cx - b.cx, dy = a.cy - b.cy;
     return dx * dx + dy * dy > reach * reach;  // NaN/inf compare false -> next filter
@@ -146,23 +149,27 @@ __device__ __forceinline__ bool surely_disjoint(const BoxPre &a, const BoxPre &b
     return sep;  // NaN / inf inputs compare false -> full path
 }
 
-// box_overlap, bev_iou_g.cu:102-206, on precomputed corners -- SIXTEEN lanes per pair.
-// As one thread per pair the clip is a dependent chain of ~2000 instructions (16 edge tests with divisions, up to 16
-// atan2f, a sort, a fan) that sets the latency of a whole tile.  Here the 16 lanes of a group split it:
-//   lane s           tests edge pair (i, j) = (s >> 2, s & 3)                       -> candidate point s      (:150-164)
-//   lanes 0..7       test one corner each: B[k] inside A (even), A[k] inside B (odd) -> candidate point 16 + s (:166-176)
+// box_overlap, bev_iou_g.cu:102-206, on precomputed corners -- EIGHT lanes per pair.
+// As one thread per pair the clip is a dependent chain of ~2000 instructions (16 edge tests with divisions, up to 24
+// atan2f, a sort, a fan) that sets the latency of a whole tile; sixteen lanes per pair (the first cooperative form) cut
+// the chain but kept every compute unit's vector ALUs busy with mostly idle lanes: the clip of ~25 surviving pairs of a
+// tile was 8 us of a 20 us kernel.  Eight lanes per pair: half the lane-instructions per pair and 32 pairs per pass of a
+// 256-thread workgroup.  The lanes of a group split the work:
+//   lane s           tests edge pairs (i, j) = (s >> 2, s & 3) and (2 + (s >> 2), s & 3) -> candidate points s, s + 8  (:150-164)
+//   lane s           tests one corner: B[s >> 1] inside A (s even), A[s >> 1] inside B (s odd) -> candidate point 16 + s (:166-176)
 //   every lane       adds up the valid points IN THE REFERENCE'S ORDER (slots 0..23 ascending) -> the same centroid bits
-//   point owners     atan2f of their point(s); rank = valid points with a smaller angle, or an equal angle and a smaller
-//                    slot (= the position the reference's stable bubble sort gives the point, :181-190)
-//   lanes 0..13      one fan term each (points of rank r, r+1 against rank 0);  the terms are then summed in rank
-//                    order, so the area has the reference's rounding sequence (:192-197).
-// Scratch per group in LDS: 24 points, 24 angles, 24 sorted slots, 16 terms.  The lanes of a group sit in one wave: the
+//   lane s           takes the s-th VALID point (s+8-th ...): its atan2f; rank = valid points with a smaller angle, or an
+//                    equal angle and a smaller slot (= the position the reference's stable bubble sort gives it, :181-190)
+//   every lane       up to three fan terms (points of rank r, r+1 against rank 0), r = s+1, s+9, s+17; the terms are
+//                    then summed in rank order, so the area has the reference's rounding sequence (:192-197).
+// Scratch per group in LDS: 24 points, 24 angles, 24 sorted slots, 24 terms.  The lanes of a group sit in one wave: the
 // LDS executes a wave's accesses in order, a compiler barrier between the steps is all the synchronisation needed.
 constexpr int kClipSlots = 24;
+constexpr int kClipLanes = 8;
 struct ClipScratch {
-    float px[kClipSlots], py[kClipSlots], ang[kClipSlots];
-    int sorted[kClipSlots];
-    float term[16];
+    float px[kClipSlots], py[kClipSlots];
+    union { float ang[kClipSlots]; float term[kClipSlots]; };   // the angles are dead once every point has its rank
+    unsigned char sorted[kClipSlots];
 };
 
 __device__ __forceinline__ void group_sync()
@@ -173,28 +180,31 @@ __device__ __forceinline__ void group_sync()
     asm volatile("" ::: "memory");
 }
 
-// all 16 lanes of a group call this together (sub = lane & 15); every lane returns the area
-__device__ float box_overlap_group(const BoxPre &pa, const BoxPre &pb, ClipScratch &cs, int sub)
+// all 8 lanes of a group call this together (sub = lane & 7); every lane returns the area
+__device__ float box_overlap_group(const BoxPre &pa, const BoxPre &pb, ClipScratch &cs, int sub, int stop = 0)
 {
-    // ---- candidate points ----
-    const int i = sub >> 2, j = sub & 3;
-    Pt x1;
-    const bool hit1 = seg_intersection(pa.cor[(i + 1) & 3], pa.cor[i], pb.cor[(j + 1) & 3], pb.cor[j], x1);
-    bool hit2 = false;
-    Pt x2 = { 0.f, 0.f };
-    if (sub < 8) {
+    // ---- candidate points: slots sub, sub + 8 (edge crossings), 16 + sub (a corner inside the other box) ----
+    const int j = sub & 3, i0 = sub >> 2, i1 = i0 + 2;
+    const Pt qa = pb.cor[(j + 1) & 3], qb = pb.cor[j];
+    Pt x[3];
+    bool hit[3];
+    hit[0] = seg_intersection(pa.cor[(i0 + 1) & 3], pa.cor[i0], qa, qb, x[0]);
+    hit[1] = seg_intersection(pa.cor[(i1 + 1) & 3], pa.cor[i1], qa, qb, x[1]);
+    {
         const int k = sub >> 1;
-        if (sub & 1) { x2 = pa.cor[k]; hit2 = in_box2d(pb.box, pb.cs, -pb.sn, x2); }   // A[k] inside B
-        else { x2 = pb.cor[k]; hit2 = in_box2d(pa.box, pa.cs, -pa.sn, x2); }          // B[k] inside A
+        if (sub & 1) { x[2] = pa.cor[k]; hit[2] = in_box2d(pb.box, pb.cs, -pb.sn, x[2]); }   // A[k] inside B
+        else { x[2] = pb.cor[k]; hit[2] = in_box2d(pa.box, pa.cs, -pa.sn, x[2]); }          // B[k] inside A
     }
-    const int row = (threadIdx.x & 63) & ~15;   // first lane of my group inside the wave
-    const unsigned m1 = static_cast<unsigned>(__ballot(hit1) >> row) & 0xffffu;
-    const unsigned m2 = static_cast<unsigned>(__ballot(hit2) >> row) & 0xffu;
-    const unsigned valid = m1 | (m2 << 16);
+    const int row = (threadIdx.x & 63) & ~(kClipLanes - 1);   // first lane of my group inside the wave
+    const unsigned valid = (static_cast<unsigned>(__ballot(hit[0]) >> row) & 0xffu) |
+                           ((static_cast<unsigned>(__ballot(hit[1]) >> row) & 0xffu) << 8) |
+                           ((static_cast<unsigned>(__ballot(hit[2]) >> row) & 0xffu) << 16);
     const int cnt = __builtin_popcount(valid);
     if (cnt < 3) return 0.0f;   // group-uniform: fewer than 3 points, the fan sums nothing but zeros
-    if (hit1) { cs.px[sub] = x1.x; cs.py[sub] = x1.y; }
-    if (hit2) { cs.px[16 + sub] = x2.x; cs.py[16 + sub] = x2.y; }
+    if (stop == 5) return 1.0f;   // diagnostics only
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        if (hit[p]) { cs.px[sub + 8 * p] = x[p].x; cs.py[sub + 8 * p] = x[p].y; }
     group_sync();
     // ---- centroid: the same sequence of additions as the reference ----
     Pt ctr = { 0.f, 0.f };
@@ -204,30 +214,44 @@ __device__ float box_overlap_group(const BoxPre &pa, const BoxPre &pb, ClipScrat
     }
     ctr.x /= cnt;
     ctr.y /= cnt;
+    if (stop == 6) return ctr.x;
     // ---- angles (point_cmp :98-100 evaluates atan2 of the point minus the centre) ----
-    float a1 = 0.f, a2 = 0.f;
-    if (hit1) { a1 = atan2f(x1.y - ctr.y, x1.x - ctr.x); cs.ang[sub] = a1; }
-    if (hit2) { a2 = atan2f(x2.y - ctr.y, x2.x - ctr.x); cs.ang[16 + sub] = a2; }
-    group_sync();
-    // ---- position of my point(s) after the reference's stable sort ----
-    int r1 = 0, r2 = 0;
-    for (unsigned m = valid; m; m &= m - 1u) {
-        const int sl = __builtin_ctz(m);
-        const float aj = cs.ang[sl];
-        r1 += (aj < a1 || (aj == a1 && sl < sub)) ? 1 : 0;
-        r2 += (aj < a2 || (aj == a2 && sl < 16 + sub)) ? 1 : 0;
+    // The valid points (6 of the 24 slots on average) are dealt out again, one per lane: lane s takes the s-th valid
+    // slot (and the (s+8)-th ... when there are more than eight), so a wave runs atan2f once, not once per slot a lane owns.
+    auto nth_valid = [&](int p) -> int {
+        unsigned m = valid;
+        for (int k = 0; k < p; ++k) m &= m - 1u;
+        return __builtin_ctz(m);
+    };
+    for (int p = sub; p < cnt; p += kClipLanes) {
+        const int sl = nth_valid(p);
+        cs.ang[sl] = atan2f(cs.py[sl] - ctr.y, cs.px[sl] - ctr.x);
     }
-    if (hit1) cs.sorted[r1] = sub;
-    if (hit2) cs.sorted[r2] = 16 + sub;
+    group_sync();
+    if (stop == 7) return cs.ang[0];
+    // ---- position of my point(s) after the reference's stable sort ----
+    for (int p = sub; p < cnt; p += kClipLanes) {
+        const int sl = nth_valid(p);
+        const float am = cs.ang[sl];
+        int rk = 0;
+        for (unsigned m = valid; m; m &= m - 1u) {
+            const int o = __builtin_ctz(m);
+            const float aj = cs.ang[o];
+            rk += (aj < am || (aj == am && o < sl)) ? 1 : 0;
+        }
+        cs.sorted[rk] = sl;
+    }
     group_sync();
     // ---- fan terms, then their sum in rank order ----
-    const int r = sub + 1;
-    if (r <= cnt - 2) {
-        const int s0 = cs.sorted[0], sk = cs.sorted[r], sn = cs.sorted[r + 1];
+    {
+        const int s0 = cs.sorted[0];
         const float x0 = cs.px[s0], y0 = cs.py[s0];
-        const float ux = cs.px[sk] - x0, uy = cs.py[sk] - y0;
-        const float vx = cs.px[sn] - x0, vy = cs.py[sn] - y0;
-        cs.term[r] = ux * vy - uy * vx;
+        for (int r = sub + 1; r <= cnt - 2; r += kClipLanes) {
+            const int sk = cs.sorted[r], sn = cs.sorted[r + 1];
+            const float ux = cs.px[sk] - x0, uy = cs.py[sk] - y0;
+            const float vx = cs.px[sn] - x0, vy = cs.py[sn] - y0;
+            cs.term[r] = ux * vy - uy * vx;
+        }
     }
     group_sync();
     float area = 0.f;
@@ -247,106 +271,206 @@ __device__ __forceinline__ float iou_from_overlap(const float *a, const float *b
 // ---------------------------------------------------------------- 64 x 64 pair tiles
 constexpr int kTileThreads = 256;
 
-struct TileShared {
-    BoxPre ra[64], cb[64];
-    unsigned short queue[64 * 64];    // pairs that passed the bounding-circle filter
-    unsigned short queue2[64 * 64];   // ... and the separating-axis filter
-    unsigned long long words[64];
-    int qcount, q2count;
-    ClipScratch clip[kTileThreads / 16];
+template <int ROWS, int THREADS>
+struct TileSharedT {
+    BoxPre ra[ROWS], cb[64];
+    union {   // the first queue is dead once the second one is complete (a barrier later the clip starts)
+        unsigned short queue[ROWS * 64];           // pairs that passed the bounding-circle filter: row << 6 | col
+        ClipScratch clip[THREADS / kClipLanes];    // one per group of lanes
+    };
+    unsigned short queue2[ROWS * 64];              // ... and the separating-axis filter
+    unsigned long long words[64];                  // NMS: the mask words of the tile's rows
+    unsigned long long apart[ROWS];                // IoU: bit 16 i + k of word r = pair (r, 4 k + i) is an exact zero by the circle filter
+    unsigned long long late[ROWS];                 // IoU: the same for the zeros of the separating-axis filter
+    int qcount, q2count, arrived;
 };
+typedef TileSharedT<64, kTileThreads> TileShared;   // the square tiles of the NMS mask
+// compute_bev_iou: 80 x 64 tiles, 512 threads (38 KB of LDS, <= 64 VGPRs: four workgroups per CU).  70 000 rows are 875 workgroups =
+// ONE round of the 1024 resident slots (64-row tiles were 1094 workgroups, and the 70 of the second round doubled the
+// kernel's duration).  Waves 0..4 clip (40 groups of eight lanes: one pass for almost every tile), waves 5..7 write the zeros.
+constexpr int kIouRows = 80;
+constexpr int kIouThreads = 512;
+constexpr int kIouStoreWaves = 3;   // a wave keeps only a handful of stores in flight: one storing wave per workgroup drains
+                                    // the zeros at 4 TB/s, two at 5
+constexpr int kIouClipThreads = kIouThreads - 64 * kIouStoreWaves;
+typedef TileSharedT<kIouRows, kIouThreads> IouShared;
 
-__device__ __forceinline__ void tile_stage(TileShared &sh, const float *boxes_r, int row0, int row_size,
+template <int ROWS, int THREADS>
+__device__ __forceinline__ void tile_stage(TileSharedT<ROWS, THREADS> &sh, const float *boxes_r, int row0, int row_size,
                                            const float *boxes_c, int col0, int col_size)
 {
     const int t = threadIdx.x;
+    // threads 0..63: the columns; threads 64..: the rows
+    static_assert(ROWS + 64 <= THREADS, "one thread per box");
     if (t < 64) {
-        if (t < row_size) box_precompute(boxes_r + static_cast<size_t>(row0 + t) * 5, sh.ra[t]);
+        if (t < col_size) box_precompute(boxes_c + static_cast<size_t>(col0 + t) * 5, sh.cb[t]);
         sh.words[t] = 0ull;
-    } else if (t < 128) {
-        const int c = t - 64;
-        if (c < col_size) box_precompute(boxes_c + static_cast<size_t>(col0 + c) * 5, sh.cb[c]);
+    } else if (t - 64 < ROWS) {
+        if (t - 64 < row_size) box_precompute(boxes_r + static_cast<size_t>(row0 + t - 64) * 5, sh.ra[t - 64]);
+        sh.apart[t - 64] = 0ull;
+        sh.late[t - 64] = 0ull;
     }
-    if (t == 128) { sh.qcount = 0; sh.q2count = 0; }
+    if (t == THREADS - 1) { sh.qcount = 0; sh.q2count = 0; sh.arrived = 0; }
 }
 
-// IoU matrix: one workgroup per 64 x 64 tile of (a, b) pairs
-__global__ __launch_bounds__(kTileThreads, 4) void bev_iou_kernel(int num_a, const float *__restrict__ boxes_a, int num_b,
-                                                               const float *__restrict__ boxes_b,
-                                                               float *__restrict__ ans_overlap,
-                                                               float *__restrict__ ans_iou, int stop)
+// IoU matrix: one workgroup per 80 x 64 tile of (a, b) pairs.
+// 99 % of the pairs are exact zeros by the first filter, and writing them (8 bytes per pair, both outputs) is the floor of
+// the kernel: ~6 us of store drain at 70 000 x 64.  A wave that issues those stores is held by the back-pressure of the
+// write path for that long -- so ONE wave (the last) issues them all, after the filters, while the other five clip the
+// ~30 pairs of the tile that do overlap.  (When every wave stored its share before the clip, the clip started after the
+// drain: 18 us.)
+__global__ __launch_bounds__(kIouThreads, 8) void bev_iou_kernel(int num_a, const float *__restrict__ boxes_a, int num_b,
+                                                              const float *__restrict__ boxes_b,
+                                                              float *__restrict__ ans_overlap,
+                                                              float *__restrict__ ans_iou, int stop)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    TileShared &sh = *reinterpret_cast<TileShared *>(smem_raw);
+    IouShared &sh = *reinterpret_cast<IouShared *>(smem_raw);
     const int t = threadIdx.x;
-    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
-    const int row_size = min(num_a - row0, 64), col_size = min(num_b - col0, 64);
+    const int row0 = blockIdx.y * kIouRows, col0 = blockIdx.x * 64;
+    const int row_size = min(num_a - row0, kIouRows), col_size = min(num_b - col0, 64);
     if (stop == 1) return;   // diagnostics only (HF_BEV_STOP): outputs invalid
     tile_stage(sh, boxes_a, row0, row_size, boxes_b, col0, col_size);
     __syncthreads();
     if (stop == 2) return;
-    // filter 1 (all pairs, cheap): bounding circles.  A thread owns four consecutive columns of a row: when all four are
-    // far apart (the usual case) the zeros leave as one 16-byte store per output
-    const bool vec = (num_b & 3) == 0;   // rows of the outputs are 16-byte aligned (the launcher checks the base pointers)
-    for (int e4 = t; e4 < 64 * 16; e4 += kTileThreads) {
-        const int r = e4 >> 4, c0 = (e4 & 15) * 4;
-        if (r >= row_size || c0 >= col_size) continue;
-        bool apart[4];
-        bool all_apart = true;
+    // filter 1 (all pairs, cheap): bounding circles.  A thread owns FOUR FIXED columns (their centre / radius / magnitude
+    // stay in registers) and walks the rows 32 apart: a quarter of a 16-byte LDS read and a handful of packed instructions per pair.
+    // Exact zeros are recorded in the tile's bitmap, the rest goes to the queue.
+    {
+        const int c0 = (t & 15) * 4;
+        // reach = (a.rad + 1e-5 a.mag) + (b.rad + 1e-3 + 1e-5 b.mag): the column half is folded once per thread, the row
+        // half once per row; pairs go two at a time through the packed fp32 instructions
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v bx[2], by[2], bs[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            apart[i] = c0 + i < col_size ? circles_apart(sh.ra[r], sh.cb[c0 + i]) : true;
-            all_apart = all_apart && apart[i];
+            const float4 q = *reinterpret_cast<const float4 *>(&sh.cb[min(c0 + i, 63)]);
+            bx[i >> 1][i & 1] = q.x; by[i >> 1][i & 1] = q.y; bs[i >> 1][i & 1] = q.z + 1e-3f + 1e-5f * q.w;
         }
-        const size_t o = static_cast<size_t>(row0 + r) * num_b + col0 + c0;
-        if (all_apart && vec && c0 + 4 <= col_size) {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ans_overlap) *reinterpret_cast<float4 *>(ans_overlap + o) = z;
-            if (ans_iou) *reinterpret_cast<float4 *>(ans_iou + o) = z;
-            continue;
-        }
+        // a wave covers four rows per step; the trip count is wave-uniform (the ballots below need every lane)
+        for (int rb = (t >> 6) * 4; rb < row_size; rb += kIouThreads / 16) {
+            const int g = (t >> 4) & 3, r = rb + g;
+            const bool live = r < row_size && c0 < col_size;
+            const float4 a = *reinterpret_cast<const float4 *>(&sh.ra[live ? r : 0]);   // cx, cy, rad, mag
+            const float as = a.z + 1e-5f * a.w;
+            unsigned m16[4];       // bit k = pair (r, 4 k + i) is far apart: the ballot bits of the 16 lanes of my row
+            unsigned surv = 0u;    // my pairs that go on to the next filter
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (c0 + i >= col_size) continue;
-            if (apart[i]) {
-                if (ans_overlap) ans_overlap[o + i] = 0.0f;
-                if (ans_iou) ans_iou[o + i] = 0.0f;
-            } else {
-                sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | (c0 + i));
+            for (int h = 0; h < 2; ++h) {
+                // = circles_apart(): centres further apart than the radius bounds plus a slack that dwarfs MARGIN and
+                // fp32 rounding; NaN / inf compare false -> next filter
+                const f2v reach = bs[h] + as;
+                const f2v dx = bx[h] - a.x, dy = by[h] - a.y;
+                const f2v d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+                const f2v r2 = reach * reach;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = 2 * h + u;
+                    const bool in = live && c0 + i < col_size;
+                    const bool far = in && d2[u] > r2[u];
+                    if (in && !far) surv |= 1u << i;
+                    const unsigned long long bal = __ballot(far);
+                    const unsigned half = (t & 32) ? static_cast<unsigned>(bal >> 32) : static_cast<unsigned>(bal);
+                    m16[i] = (half >> (t & 16)) & 0xffffu;
+                }
+            }
+            for (; surv; surv &= surv - 1u)   // about one pair in a hundred
+                sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | (c0 + __builtin_ctz(surv)));
+            const unsigned long long word = (static_cast<unsigned long long>(m16[2] | (m16[3] << 16)) << 32) | (m16[0] | (m16[1] << 16));
+            if (live && (t & 15) == 0) sh.apart[r] = word;
+        }
+    }
+    __syncthreads();   // the only barrier after the staging: from here on the storing wave and the clipping waves part
+    if (stop == 3) return;
+    if (t >= kIouClipThreads) {
+        // the zeros of filter 1: lane -> (one of four rows, four columns); a full nibble leaves as one 16-byte store per
+        // output (rows of the outputs are 16-byte aligned when num_b is a multiple of 4; the launcher checks the bases)
+        if (stop == 8) return;   // diagnostics only: no zeros written
+        const bool vec = (num_b & 3) == 0;
+        const int l = t & 63, k = l & 15, c0 = k * 4, sw = (t - kIouClipThreads) >> 6;
+        constexpr int kStep = 4 * kIouStoreWaves;   // rows between two visits of a lane
+        // wait for the separating-axis filter of the clipping waves (well under a microsecond): its zeros then leave with
+        // the rest, in full 16-byte stores where the whole nibble is zero
+        while (__hip_atomic_load(&sh.arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kIouClipThreads / 64) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        if (c0 < col_size) {
+            constexpr int kBatch = 5;   // rows per lane and batch: the bitmap words first, then the stores back to back
+            for (int rb = (l >> 4) + 4 * sw; rb < row_size; rb += kStep * kBatch) {
+                unsigned long long w[kBatch];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int r = min(rb + kStep * j, kIouRows - 1);
+                    w[j] = (sh.apart[r] | sh.late[r]) >> k;
+                }
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int r = rb + kStep * j;
+                    if (r >= row_size) break;
+                    const unsigned nib = static_cast<unsigned>(w[j] & 1ull) | (static_cast<unsigned>(w[j] >> 15) & 2u) |
+                                         (static_cast<unsigned>(w[j] >> 30) & 4u) | (static_cast<unsigned>(w[j] >> 45) & 8u);
+                    const size_t o = static_cast<size_t>(row0 + r) * num_b + col0 + c0;
+                    if (nib == 15u && vec) {
+                        typedef float f4v __attribute__((ext_vector_type(4)));
+                        const f4v z = { 0.f, 0.f, 0.f, 0.f };
+                        if (ans_overlap) __builtin_nontemporal_store(z, reinterpret_cast<f4v *>(ans_overlap + o));
+                        if (ans_iou) __builtin_nontemporal_store(z, reinterpret_cast<f4v *>(ans_iou + o));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if ((nib >> i) & 1u) {
+                                if (ans_overlap) ans_overlap[o + i] = 0.0f;
+                                if (ans_iou) ans_iou[o + i] = 0.0f;
+                            }
+                    }
+                }
             }
         }
+        return;
     }
-    __syncthreads();
-    if (stop == 3) return;
-    // filter 2 (survivors only, dense lanes): separating axes -> exact zeros or the second queue
+    // filter 2 (survivors only, dense lanes, the clipping waves): separating axes -> exact zeros or the second queue
     const int nq = sh.qcount;
-    for (int q = t; q < nq; q += kTileThreads) {
+    for (int q = t; q < nq; q += kIouClipThreads) {
         const int e = sh.queue[q];
         const int r = e >> 6, c = e & 63;
-        if (surely_disjoint(sh.ra[r], sh.cb[c])) {
-            const size_t o = static_cast<size_t>(row0 + r) * num_b + col0 + c;
-            if (ans_overlap) ans_overlap[o] = 0.0f;
-            if (ans_iou) ans_iou[o] = 0.0f;
-        } else {
-            sh.queue2[atomicAdd(&sh.q2count, 1)] = static_cast<unsigned short>(e);
+        if (surely_disjoint(sh.ra[r], sh.cb[c])) atomicOr(&sh.late[r], 1ull << (16 * (c & 3) + (c >> 2)));   // written by the storing waves
+        else sh.queue2[atomicAdd(&sh.q2count, 1)] = static_cast<unsigned short>(e);
+    }
+    // the clipping waves meet here (the sixth is busy storing and must not be waited for): an arrival counter in LDS.
+    // All five are resident and all five get here, so the wait is bounded.
+    // Only LDS traffic has to be ordered: a workgroup-scope fence would also wait for this wave's global stores (the
+    // zeros of filter 2), and those sit behind the storing waves' megabytes in the write path.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((t & 63) == 0) __hip_atomic_fetch_add(&sh.arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(&sh.arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kIouClipThreads / 64) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    if (stop == 4) return;
+    // the clip on what is left: eight lanes per pair, 40 pairs per pass.  The results of the first two passes wait in
+    // registers until the group has clipped its last pair: their stores, too, could stall the wave while the zeros drain.
+    const int nq2 = sh.q2count;
+    const int grp = t / kClipLanes, sub = t % kClipLanes;
+    int held_e[2] = { -1, -1 };
+    float held_s[2] = { 0.f, 0.f };
+    auto write_pair = [&](int e, float sv) {
+        const int r = e >> 6, c = e & 63;
+        const size_t o = static_cast<size_t>(row0 + r) * num_b + col0 + c;
+        if (ans_overlap) ans_overlap[o] = sv;
+        if (ans_iou) ans_iou[o] = iou_from_overlap(sh.ra[r].box, sh.cb[c].box, sv);
+    };
+    int pass = 0;
+    for (int q0 = 0; q0 < nq2; q0 += kIouClipThreads / kClipLanes, ++pass) {
+        const int q = q0 + grp;
+        if (q >= nq2) break;   // whole groups leave together
+        const int e = sh.queue2[q];
+        const float sv = box_overlap_group(sh.ra[e >> 6], sh.cb[e & 63], sh.clip[grp], sub, stop);
+        if (sub == 0) {
+            if (pass == 0) { held_e[0] = e; held_s[0] = sv; }
+            else if (pass == 1) { held_e[1] = e; held_s[1] = sv; }
+            else write_pair(e, sv);
         }
     }
-    __syncthreads();
-    // the clip on what is left: sixteen lanes per pair, sixteen pairs per pass
-    if (stop == 4) return;
-    const int nq2 = sh.q2count;
-    const int grp = t >> 4, sub = t & 15;
-    for (int q0 = 0; q0 < nq2; q0 += kTileThreads / 16) {
-        const int q = q0 + grp;
-        if (q >= nq2) continue;   // whole groups leave together
-        const int e = sh.queue2[q];
-        const int r = e >> 6, c = e & 63;
-        const float s = box_overlap_group(sh.ra[r], sh.cb[c], sh.clip[grp], sub);
-        if (sub == 0) {
-            const size_t o = static_cast<size_t>(row0 + r) * num_b + col0 + c;
-            if (ans_overlap) ans_overlap[o] = s;
-            if (ans_iou) ans_iou[o] = iou_from_overlap(sh.ra[r].box, sh.cb[c].box, s);
-        }
+    if (sub == 0) {
+        if (held_e[0] >= 0) write_pair(held_e[0], held_s[0]);
+        if (held_e[1] >= 0) write_pair(held_e[1], held_s[1]);
     }
 }
 
@@ -402,8 +526,8 @@ __global__ __launch_bounds__(kNmsThreads, 4) void nms_mask_kernel(int n, float t
     __syncthreads();
     {
         const int nq2 = sh.q2count;
-        const int grp = t >> 4, sub = t & 15;
-        for (int q0 = 0; q0 < nq2; q0 += kNmsThreads / 16) {
+        const int grp = t / kClipLanes, sub = t % kClipLanes;
+        for (int q0 = 0; q0 < nq2; q0 += kNmsThreads / kClipLanes) {
             const int q = q0 + grp;
             if (q >= nq2) continue;   // whole groups leave together
             const int e = sh.queue2[q];
@@ -571,12 +695,12 @@ using namespace hf;
 
 // the pair-tile kernels keep their state (and the clip's point arrays) in dynamic LDS: ~33 KB, four workgroups per CU
 template <typename K>
-static void tile_lds_attr(K kernel)
+static void tile_lds_attr(K kernel, size_t bytes = sizeof(TileShared))
 {
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(sizeof(TileShared)));
+                                  static_cast<int>(bytes));
         done = true;
     }
 }
@@ -587,8 +711,8 @@ HF_API int hf_compute_bev_iou(int num_a, const float *boxes_a, int num_b, const 
     // ComputeBevIOUOp: N > 0, M > 0, (N,5) / (M,5)  (bev_iou.cpp:156-157)
     if (num_a <= 0 || num_b <= 0 || !boxes_a || !boxes_b) return HF_EINVAL;
     if (!ans_overlap && !ans_iou) return HF_OK;
-    const int gy = (num_a + 63) / 64, gx = (num_b + 63) / 64;
-    tile_lds_attr(&bev_iou_kernel);
+    const int gy = (num_a + kIouRows - 1) / kIouRows, gx = (num_b + 63) / 64;
+    tile_lds_attr(&bev_iou_kernel, sizeof(IouShared));
     const char *stop_env = getenv("HF_BEV_STOP");   // diagnostics only: early exit after a phase (outputs invalid)
     const int stop = stop_env && stop_env[0] ? atoi(stop_env) : 0;
     if ((ans_overlap && reinterpret_cast<uintptr_t>(ans_overlap) % 16 != 0) || (ans_iou && reinterpret_cast<uintptr_t>(ans_iou) % 16 != 0))
@@ -596,16 +720,16 @@ HF_API int hf_compute_bev_iou(int num_a, const float *boxes_a, int num_b, const 
     if (gy > 65535) {
         // very tall matrices: walk the rows in slabs of 65535 tiles
         for (int y0 = 0; y0 < gy; y0 += 65535) {
-            const int rows0 = y0 * 64;
-            const int na = std::min(num_a - rows0, 65535 * 64);
-            hipLaunchKernelGGL(bev_iou_kernel, dim3(gx, (na + 63) / 64), dim3(kTileThreads), sizeof(TileShared), as_stream(stream), na,
+            const int rows0 = y0 * kIouRows;
+            const int na = std::min(num_a - rows0, 65535 * kIouRows);
+            hipLaunchKernelGGL(bev_iou_kernel, dim3(gx, (na + kIouRows - 1) / kIouRows), dim3(kIouThreads), sizeof(IouShared), as_stream(stream), na,
                                boxes_a + static_cast<size_t>(rows0) * 5, num_b, boxes_b,
                                ans_overlap ? ans_overlap + static_cast<size_t>(rows0) * num_b : nullptr,
                                ans_iou ? ans_iou + static_cast<size_t>(rows0) * num_b : nullptr, stop);
         }
         return launch_status();
     }
-    hipLaunchKernelGGL(bev_iou_kernel, dim3(gx, gy), dim3(kTileThreads), sizeof(TileShared), as_stream(stream), num_a, boxes_a, num_b,
+    hipLaunchKernelGGL(bev_iou_kernel, dim3(gx, gy), dim3(kIouThreads), sizeof(IouShared), as_stream(stream), num_a, boxes_a, num_b,
                        boxes_b, ans_overlap, ans_iou, stop);
     return launch_status();
 }

@@ -53,7 +53,11 @@ res["nms_mask_alone_clustered_us"] = wall(lambda: hf.oriented_nms(nbc, 0.01))
 os.environ.pop("HF_NMS_STOP")
 print(json.dumps(res, indent=1))
 if os.environ.get("PHASES"):
-    for stop in (1, 2, 3, 4, 0):
+    # cumulative kernel time up to a phase boundary (HF_BEV_STOP: 1 launch only, 2 + box precompute, 3 + circle filter and
+    # zero stores, 4 + separating-axis filter, 0 everything)
+    # 5: + edge crossings / corners of the clip, 6: + centroid, 7: + angles
+    # 8: everything but the zero stores
+    for stop in (1, 2, 3, 4, 5, 6, 7, 8, 0):
         os.environ["HF_BEV_STOP"] = str(stop)
-        print("bev_iou stop", stop, round(time_op(lambda: hf.compute_bev_iou(a, g), iters=50), 2), "us")
+        print("bev_iou stop", stop, burst_bev(70000), "us", " half grid:", burst_bev(32768), "us")
     os.environ.pop("HF_BEV_STOP")

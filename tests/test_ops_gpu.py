@@ -586,6 +586,21 @@ def test_full_size_bev_iou_properties(hf):
     np.testing.assert_allclose(np.diag(host(self_iou)), 1.0, atol=TOL)
 
 
+@pytest.mark.parametrize("thresh", [0.5, 0.9])
+def test_oracle_nms_dense_columns(hf, oracle_mod, thresh):
+    """2300 jittered copies of ONE box: every mask word is nonzero, so the per-column-block lists of the sweep
+    (2048 entries) overflow and the last columns are gathered from the dense mask instead"""
+    rng = np.random.default_rng(11)
+    boxes = _clustered(rng, 1, 2300)
+    keep, num = hf.oriented_nms(dev(boxes), thresh, return_count=True)
+    ok, okept = oracle_mod.oriented_nms(boxes, thresh, return_count=True)
+    if not np.array_equal(host(keep), ok):
+        _, iou = oracle_mod.compute_bev_iou(boxes, boxes)
+        assert np.any(np.abs(iou - thresh) < TOL), "keep differs without a borderline IoU"
+        pytest.skip("borderline IoU within 1e-5 of the threshold in this random case")
+    assert int(host(num)[0]) == okept
+
+
 def test_full_size_nms_properties(hf):
     """N=9000 (rpn_multiclass.config:25): kept set is an independent set, every dropped box is covered"""
     rng = np.random.default_rng(4)
