@@ -764,6 +764,7 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
     // OrientedNMSOp: nms_threshold >= 0 (bev_iou.cpp:52), N > 0 (:65)
     if (frames <= 0 || frames > 65535 || n <= 0 || !(thresh >= 0.0f) || !boxes || !keep) return HF_EINVAL;
     if (!workspace || workspace_bytes < static_cast<size_t>(frames) * hf_oriented_nms_workspace(n)) return HF_EWORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return HF_EINVAL;   // the list entries are read 16 bytes at a time
     const int cb = (n + 63) / 64;
     // LDS: kept bits + removal words per block, and the diagonal words of a chunk of blocks (all of them up to 8192 boxes)
     const int chunk_blocks = std::min(cb, 128);

@@ -136,7 +136,11 @@ int hf_nms_mask(const float *boxes, unsigned long long *mask, int boxes_num, flo
 /* The whole OrientedNMSOp::Compute (bev_iou.cpp:60-116) without its cudaMalloc / blocking D2H /
  * host sweep / H2D: mask kernel + device-resident greedy sweep.  boxes are score-sorted (N,5);
  * keep (N) int32 = kept indices ascending, tail padded with keep[0]; *num_kept (device int,
- * may be NULL) = count before padding.  thresh >= 0, n > 0 required. */
+ * may be NULL) = count before padding.  thresh >= 0, n > 0 required.
+ * Workspace per frame (hf_oriented_nms_workspace(n) bytes, a multiple of 256; the base 16-byte aligned): the dense
+ * mask (n * ceil(n/64) words), then -- each part padded to 256 bytes -- one counter per column block, one list of
+ * 2048 (word, row) entries per column block (the nonzero words right of the diagonal, what the sweep reads), and the
+ * n transposed diagonal words.  About 1.5x the dense mask at n = 9000 (14.8 MB). */
 size_t hf_oriented_nms_workspace(int n);
 int hf_oriented_nms(const float *boxes, int n, float thresh, int *keep, int *num_kept, void *workspace,
                     size_t workspace_bytes, hf_stream_t stream);

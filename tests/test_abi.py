@@ -37,7 +37,9 @@ def test_version_and_strerror():
     assert b"invalid" in L.hf_strerror(-1)
     assert L.hf_fps_onchip_limit() == 16384
     assert L.hf_fps_workspace(8, 16384) == 0 and L.hf_fps_workspace(2, 20000) == 2 * 20000 * 4
-    assert L.hf_oriented_nms_workspace(9000) == 9000 * 141 * 8
+    pad = lambda b: (b + 255) & ~255
+    # dense mask + per-column-block counters + per-column-block lists (2048 x 16 bytes) + transposed diagonal words
+    assert L.hf_oriented_nms_workspace(9000) == pad(9000 * 141 * 8) + pad(141 * 4) + 141 * 2048 * 16 + pad(9000 * 8)
 
 
 def test_no_cpu_fallback():
