@@ -145,7 +145,11 @@ def knn_point(k, xyz1, xyz2, all_pairs=False):
     Reference: tf_grouping.py:62-95 (dense |q|^2 - 2 q.p^T + |p|^2 matrix + tf.nn.top_k).  For C == 3 this is
     the HIP kNN kernel (no (B,M,N) matrix; ties: lower index first): data binned into a 2-D grid + ring search for
     N <= 65536, the tiled all-pairs kernel beyond that or with all_pairs=True.  Other channel counts keep the
-    reference's three-term formula in torch."""
+    reference's three-term formula in torch.
+    PARITY UNPINNED against the reference where it matters for ties: the reference ranks the fp32 three-term expansion
+    with tf.nn.top_k, this kernel ranks (q - p)^2 summed per axis with ties to the lower index.  The neighbour sets agree
+    wherever the k-th and (k+1)-th distances differ by more than the rounding of the expansion; the order among exact
+    ties / near-ties has no fixture in the reference and TensorFlow is not available here."""
     k = int(k)
     require(k > 0, "knn_point expects positive k")
     require(xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[0] == xyz2.shape[0] and

@@ -121,6 +121,8 @@ def select_top_k(k, dist):
 
 
 def knn_point(k, xyz1, xyz2):
+    """tf_grouping.py:62-95 restated with (q - p)^2 per axis and ties to the lower index: PARITY UNPINNED against the
+    reference's three-term expansion + tf.nn.top_k for exact ties and near-ties (no fixture, no TensorFlow here)."""
     xyz1, xyz2 = _f(xyz1), _f(xyz2)
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
