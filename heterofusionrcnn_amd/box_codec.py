@@ -12,8 +12,22 @@ from . import _lib
 from ._lib import check, dev_tensor, ptr, require, stream_ptr
 
 
-def _f32(device, values):
-    return torch.as_tensor(np.asarray(values, dtype=np.float64).astype(np.float32), device=device)
+_CONSTS = {}
+
+
+def const_f32(device, values):
+    """Small fp32 constant on the device, uploaded ONCE per (device, values): a pageable host-to-device copy is a
+    synchronising call, and one of them per step makes the whole train step wait for the device."""
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).astype(np.float32))
+    key = (str(device), a.shape, a.tobytes())
+    t = _CONSTS.get(key)
+    if t is None:
+        t = torch.as_tensor(a, device=device)
+        _CONSTS[key] = t
+    return t
+
+
+_f32 = const_f32
 
 
 def _theta(ref_theta, rows, device):
@@ -83,7 +97,7 @@ def decode_head(head, ref_pts, ref_theta, mean_sizes_k, num_bin_x, num_bin_z, nu
     lead = tuple(ref_pts.shape[:-1])
     rows = int(np.prod(lead)) if lead else 0
     dev = ref_pts.device
-    ms = torch.as_tensor(np.asarray(mean_sizes_k, dtype=np.float32), device=dev) if not isinstance(mean_sizes_k, torch.Tensor) \
+    ms = const_f32(dev, mean_sizes_k) if not isinstance(mean_sizes_k, torch.Tensor) \
         else dev_tensor(mean_sizes_k.detach(), torch.float32, "mean_sizes_k")
     require(ms.dim() == 2 and ms.shape[1] == 3, "mean_sizes_k must be (K, 3)")
     k = ms.shape[0]

@@ -319,7 +319,7 @@ def rpn_targets(cfg: RpnConfig, xyz, label_cls, label_reg):
     the labelled class.  Background points get class index 0: they are masked out of every box loss."""
     k = cfg.num_classes
     cls0 = torch.clamp(label_cls.long() - 1, min=0)                          # (B,P)
-    sizes = torch.as_tensor(np.asarray(cfg.cluster_sizes, np.float32), device=xyz.device)
+    sizes = box_codec.const_f32(xyz.device, cfg.cluster_sizes)   # uploaded once: no host-to-device copy inside the step
     mean_sizes = sizes[cls0]                                                 # (B,P,3)
     bin_x, res_x, bin_z, res_z, bin_t, res_t, res_y, res_size = box_codec.encode(
         xyz, 0, label_reg, mean_sizes, cfg.xz_search_range, cfg.xz_bin_len, cfg.r_theta, cfg.delta_theta, k)
