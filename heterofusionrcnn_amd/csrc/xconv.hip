@@ -1,0 +1,325 @@
+// xconv.hip -- the two per-point products of PointCNN's X-Conv (hf/core/feature_extractors/pointcnn.py:16-151) for gfx950.
+//
+//   X-transform apply   F_X = X x F_*      pointcnn.py:133  tf.matmul(X, nn_fts_input): per representative point a (K,K)
+//                                          matrix times the (K,C) block of lifted + gathered neighbour features
+//   depthwise (1,K)     pointfly.py:437-457 depthwise_conv2d / the depthwise half of separable_conv2d with a (1,K) window
+//                                          over a width-K input: out[c*M + m] = sum_w in[w][c] * W[w][c][m]
+//
+// In the reference both are library calls on tiny operands: a batched GEMM with 131 072 batches of 8x8 @ 8xC, and a
+// depthwise convolution whose window covers its whole input.  The framework route costs a third of the PointCNN RPN
+// step (batched-GEMM kernels at ~1.4 ms per layer, strided copies around every einsum).  Both are memory-bound by
+// nature: every operand is read once and every result written once, the K*K (or K*M) coefficients of a point live in
+// scalar registers / LDS.  fp32, multiply then add in index order (no FMA contraction), like the rest of the library.
+#include "hf_common.h"
+
+namespace hf {
+
+constexpr int kXcThreads = 256;
+
+// out[r][i][ch] = sum_j X[r][i][j] * F[r][j][ch]   (TRANSPOSED: sum_j X[r][j][i] * F[r][j][ch], the dF of the backward)
+// One wave per row at a time: the row's K*K coefficients are wave-uniform (scalar loads), lanes walk the channels.
+template <int K, bool TRANSPOSED>
+__global__ __launch_bounds__(kXcThreads) void xconv_apply_kernel(long long rows, int c, const float *__restrict__ x,
+                                                                const float *__restrict__ f, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) +
+                           static_cast<long long>(blockIdx.x) * (kXcThreads / 64);
+    const long long nwaves = static_cast<long long>(gridDim.x) * (kXcThreads / 64);
+    for (long long r = wave; r < rows; r += nwaves) {
+        const float *xr = x + r * (K * K);
+        float coef[K][K];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) coef[i][j] = TRANSPOSED ? xr[j * K + i] : xr[i * K + j];
+        const float *fr = f + r * K * c;
+        float *orow = out + r * K * c;
+        for (int ch = lane; ch < c; ch += 64) {
+            float v[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) v[j] = fr[static_cast<size_t>(j) * c + ch];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float acc = coef[i][0] * v[0];
+#pragma unroll
+                for (int j = 1; j < K; ++j) acc = acc + coef[i][j] * v[j];
+                orow[static_cast<size_t>(i) * c + ch] = acc;
+            }
+        }
+    }
+}
+
+// dX[r][i][j] = sum_ch dO[r][i][ch] * F[r][j][ch]: a wave per row; every lane accumulates the K*K products of its
+// channels, the 64 partial matrices meet in LDS (stride K*K + 1: conflict-free both ways) and lane p sums entry p.
+template <int K>
+__global__ __launch_bounds__(kXcThreads) void xconv_dx_kernel(long long rows, int c, const float *__restrict__ grad_out,
+                                                             const float *__restrict__ f, float *__restrict__ grad_x)
+{
+    extern __shared__ float lds[];
+    constexpr int KK = K * K, STRIDE = KK + 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float *mine = lds + static_cast<size_t>(w) * 64 * STRIDE;
+    const long long wave = w + static_cast<long long>(blockIdx.x) * (kXcThreads / 64);
+    const long long nwaves = static_cast<long long>(gridDim.x) * (kXcThreads / 64);
+    for (long long r = wave; r < rows; r += nwaves) {
+        const float *gr = grad_out + r * K * c;
+        const float *fr = f + r * K * c;
+        float acc[K][K];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[i][j] = 0.f;
+        for (int ch = lane; ch < c; ch += 64) {
+            float g[K], v[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) { g[j] = gr[static_cast<size_t>(j) * c + ch]; v[j] = fr[static_cast<size_t>(j) * c + ch]; }
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[i][j] = acc[i][j] + g[i] * v[j];
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) mine[lane * STRIDE + i * K + j] = acc[i][j];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int p = lane; p < KK; p += 64) {
+            float s = 0.f;
+            for (int l = 0; l < 64; ++l) s = s + mine[l * STRIDE + p];
+            grad_x[r * KK + p] = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// depthwise (1,K): y[r][ch*M + m] = sum_w x[r][w][ch] * W[w][ch][m]; one thread per (row, channel)
+template <int K, int M>
+__global__ __launch_bounds__(kXcThreads) void depthwise_fwd_kernel(long long rows, int c, const float *__restrict__ x,
+                                                                  const float *__restrict__ wgt, float *__restrict__ y)
+{
+    const long long total = rows * c;
+    for (long long g = static_cast<long long>(blockIdx.x) * kXcThreads + threadIdx.x; g < total;
+         g += static_cast<long long>(gridDim.x) * kXcThreads) {
+        const long long r = g / c;
+        const int ch = static_cast<int>(g - r * c);
+        float acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = 0.f;
+#pragma unroll
+        for (int w = 0; w < K; ++w) {
+            const float xv = x[(r * K + w) * c + ch];
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[m] = acc[m] + xv * wgt[(static_cast<size_t>(w) * c + ch) * M + m];
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) y[g * M + m] = acc[m];
+    }
+}
+
+// dx[r][w][ch] = sum_m dy[r][ch*M + m] * W[w][ch][m]
+template <int K, int M>
+__global__ __launch_bounds__(kXcThreads) void depthwise_dx_kernel(long long rows, int c, const float *__restrict__ grad_y,
+                                                                 const float *__restrict__ wgt, float *__restrict__ grad_x)
+{
+    const long long total = rows * c;
+    for (long long g = static_cast<long long>(blockIdx.x) * kXcThreads + threadIdx.x; g < total;
+         g += static_cast<long long>(gridDim.x) * kXcThreads) {
+        const long long r = g / c;
+        const int ch = static_cast<int>(g - r * c);
+        float gy[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) gy[m] = grad_y[g * M + m];
+#pragma unroll
+        for (int w = 0; w < K; ++w) {
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc = acc + gy[m] * wgt[(static_cast<size_t>(w) * c + ch) * M + m];
+            grad_x[(r * K + w) * c + ch] = acc;
+        }
+    }
+}
+
+// dW[w][ch][m] = sum_r x[r][w][ch] * dy[r][ch*M + m]: thread (row chunk, channel) sums its rows in registers, then one
+// atomic per coefficient and chunk (grad_w zero-filled by the entry point).  The order of the chunks is not fixed: the
+// sum is reproducible to fp32 rounding, not bit for bit.
+template <int K, int M>
+__global__ __launch_bounds__(kXcThreads) void depthwise_dw_kernel(long long rows, int c, int rows_per_chunk,
+                                                                 const float *__restrict__ x, const float *__restrict__ grad_y,
+                                                                 float *__restrict__ grad_w)
+{
+    // narrow layers (the X-transform has 8 channels): the threads a block has beyond the channels split the chunk's rows,
+    // their partial sums meet in LDS, and the block issues ONE atomic per coefficient (8 x 8 x 8 coefficients hit by a
+    // thousand blocks x 32 row slots each were 16 M atomics on 512 addresses: 7.6 ms)
+    extern __shared__ float red[];   // [K * M][cw] when nrs > 1
+    const int cw = c < kXcThreads ? c : kXcThreads, nrs = kXcThreads / cw;
+    const int t = static_cast<int>(threadIdx.x);
+    const int cl = t % cw, ch = blockIdx.x * cw + cl, rs = t / cw;
+    const bool live = ch < c && rs < nrs;
+    if (nrs > 1) {
+        for (int i = t; i < K * M * cw; i += kXcThreads) red[i] = 0.f;
+        __syncthreads();
+    }
+    const long long r0 = static_cast<long long>(blockIdx.y) * rows_per_chunk + rs;
+    const long long r1 = static_cast<long long>(blockIdx.y + 1) * rows_per_chunk < rows ? static_cast<long long>(blockIdx.y + 1) * rows_per_chunk : rows;
+    float acc[K][M];
+#pragma unroll
+    for (int w = 0; w < K; ++w)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[w][m] = 0.f;
+    if (live) {
+        for (long long r = r0; r < r1; r += nrs) {
+            float gy[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) gy[m] = grad_y[(r * c + ch) * M + m];
+#pragma unroll
+            for (int w = 0; w < K; ++w) {
+                const float xv = x[(r * K + w) * c + ch];
+#pragma unroll
+                for (int m = 0; m < M; ++m) acc[w][m] = acc[w][m] + xv * gy[m];
+            }
+        }
+    }
+    if (nrs == 1) {
+        if (live) {
+#pragma unroll
+            for (int w = 0; w < K; ++w)
+#pragma unroll
+                for (int m = 0; m < M; ++m) atomicAdd(&grad_w[(static_cast<size_t>(w) * c + ch) * M + m], acc[w][m]);
+        }
+        return;
+    }
+    if (live) {
+#pragma unroll
+        for (int w = 0; w < K; ++w)
+#pragma unroll
+            for (int m = 0; m < M; ++m) atomicAdd(&red[(w * M + m) * cw + cl], acc[w][m]);
+    }
+    __syncthreads();
+    for (int i = t; i < K * M * cw; i += kXcThreads) {
+        const int wm = i / cw, c2 = blockIdx.x * cw + i % cw;
+        if (c2 < c) atomicAdd(&grad_w[(static_cast<size_t>(wm / M) * c + c2) * M + wm % M], red[i]);
+    }
+}
+
+static int grid_for(long long items, int per_block)
+{
+    const long long blocks = (items + per_block - 1) / per_block;
+    return static_cast<int>(blocks < 1 ? 1 : (blocks > 8 * kNumCU ? 8 * kNumCU : blocks));
+}
+
+template <int K>
+static int launch_apply(long long rows, int c, const float *x, const float *f, float *out, bool transposed, hipStream_t st)
+{
+    const int grid = grid_for(rows, kXcThreads / 64);
+    if (transposed) hipLaunchKernelGGL((xconv_apply_kernel<K, true>), dim3(grid), dim3(kXcThreads), 0, st, rows, c, x, f, out);
+    else hipLaunchKernelGGL((xconv_apply_kernel<K, false>), dim3(grid), dim3(kXcThreads), 0, st, rows, c, x, f, out);
+    return launch_status();
+}
+
+template <int K>
+static int launch_dx(long long rows, int c, const float *grad_out, const float *f, float *grad_x, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * (kXcThreads / 64) * 64 * (K * K + 1);
+    static bool raised = false;
+    if (!raised && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dx_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+        raised = true;
+    }
+    hipLaunchKernelGGL((xconv_dx_kernel<K>), dim3(grid_for(rows, kXcThreads / 64)), dim3(kXcThreads), lds, st, rows, c, grad_out, f,
+                       grad_x);
+    return launch_status();
+}
+
+}  // namespace hf
+
+using namespace hf;
+
+HF_API int hf_xconv_apply(long long rows, int k, int c, const float *x, const float *f, float *out, hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !f || !out) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    switch (k) {
+    case 4: return launch_apply<4>(rows, c, x, f, out, false, as_stream(stream));
+    case 8: return launch_apply<8>(rows, c, x, f, out, false, as_stream(stream));
+    default: return HF_EINVAL;   // K of the shipped configs is 8 (rpn_multiclass.config:67-112); other K: the caller's GEMM route
+    }
+}
+
+HF_API int hf_xconv_apply_grad(long long rows, int k, int c, const float *x, const float *f, const float *grad_out,
+                               float *grad_x, float *grad_f, hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !f || !grad_out || (!grad_x && !grad_f)) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    hipStream_t st = as_stream(stream);
+    int rc = HF_OK;
+#define HF_XC_CASE(KK)                                                                                                 \
+    case KK:                                                                                                           \
+        if (grad_f) rc = launch_apply<KK>(rows, c, x, grad_out, grad_f, true, st);                                     \
+        if (rc == HF_OK && grad_x) rc = launch_dx<KK>(rows, c, grad_out, f, grad_x, st);                               \
+        return rc;
+    switch (k) {
+        HF_XC_CASE(4)
+        HF_XC_CASE(8)
+    default: return HF_EINVAL;
+    }
+#undef HF_XC_CASE
+}
+
+// (k, m) pairs instantiated: the depthwise steps of the X-transform are (K, K) -> K*K with m = K; the separable
+// convolutions use depth multipliers 1..4 (pointcnn.py:259-265)
+#define HF_DW_DISPATCH(CALL)                                                                                           \
+    if (k == 8 && m == 1) { CALL(8, 1) } else if (k == 8 && m == 2) { CALL(8, 2) } else if (k == 8 && m == 3) { CALL(8, 3) }      \
+    else if (k == 8 && m == 4) { CALL(8, 4) } else if (k == 8 && m == 8) { CALL(8, 8) }                                 \
+    else if (k == 4 && m == 1) { CALL(4, 1) } else if (k == 4 && m == 4) { CALL(4, 4) }                                 \
+    else return HF_EINVAL;
+
+HF_API int hf_depthwise_k(long long rows, int k, int c, int m, const float *x, const float *w, float *y, hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !w || !y) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    const int grid = grid_for(rows * c, kXcThreads);
+#define HF_DW_FWD(KK, MM) hipLaunchKernelGGL((depthwise_fwd_kernel<KK, MM>), dim3(grid), dim3(kXcThreads), 0, as_stream(stream), rows, c, x, w, y);
+    HF_DW_DISPATCH(HF_DW_FWD)
+#undef HF_DW_FWD
+    return launch_status();
+}
+
+HF_API int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float *x, const float *w, const float *grad_y,
+                               float *grad_x, float *grad_w, hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !w || !grad_y || (!grad_x && !grad_w)) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (grad_w) {
+        const int rc = hip_status(hipMemsetAsync(grad_w, 0, sizeof(float) * static_cast<size_t>(k) * c * m, st));
+        if (rc != HF_OK) return rc;
+    }
+    if (rows == 0) return HF_OK;
+    if (grad_x) {
+        const int grid = grid_for(rows * c, kXcThreads);
+#define HF_DW_DX(KK, MM) hipLaunchKernelGGL((depthwise_dx_kernel<KK, MM>), dim3(grid), dim3(kXcThreads), 0, st, rows, c, grad_y, w, grad_x);
+        HF_DW_DISPATCH(HF_DW_DX)
+#undef HF_DW_DX
+        const int rc = launch_status();
+        if (rc != HF_OK) return rc;
+    }
+    if (grad_w) {
+        // enough chunks to fill the chip, few enough that the atomics stay a footnote
+        const int cblocks = c < kXcThreads ? 1 : div_up(c, kXcThreads);
+        const size_t lds = c <= kXcThreads / 2 ? sizeof(float) * static_cast<size_t>(k) * m * c : 0;   // block-level reduction when a block holds >= 2 row slots
+        if (lds > 48 * 1024) return HF_EINVAL;
+        long long chunks = (2 * kNumCU + cblocks - 1) / cblocks;
+        if (chunks > rows) chunks = rows;
+        if (chunks > 65535) chunks = 65535;
+        const int rows_per_chunk = static_cast<int>((rows + chunks - 1) / chunks);
+        const dim3 grid(cblocks, static_cast<unsigned>((rows + rows_per_chunk - 1) / rows_per_chunk));
+#define HF_DW_DW(KK, MM) hipLaunchKernelGGL((depthwise_dw_kernel<KK, MM>), grid, dim3(kXcThreads), lds, st, rows, c, rows_per_chunk, x, grad_y, grad_w);
+        HF_DW_DISPATCH(HF_DW_DW)
+#undef HF_DW_DW
+        return launch_status();
+    }
+    return HF_OK;
+}

@@ -28,6 +28,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+from ._lib import check, ptr, stream_ptr
 from .grouping import group_point, knn_point
 from .sampling import farthest_point_sample, gather_point
 from .mlp import BatchNormReLU
@@ -62,11 +64,83 @@ class Dense(nn.Module):
         return self.post(self.linear(x))
 
 
+_XAPPLY_K = (4, 8)                                             # K with a HIP kernel (csrc/xconv.hip); shipped configs: 8
+_DEPTHWISE_KM = {(8, 1), (8, 2), (8, 3), (8, 4), (8, 8), (4, 1), (4, 4)}
+
+
+def _hip_ok(*tensors):
+    return all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+class _DepthwiseK(torch.autograd.Function):
+    """hf_depthwise_k / hf_depthwise_k_grad: one pass over x, no permuted temporaries (the einsum route copies x twice)"""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        k, c, m = weight.shape
+        x2 = x.reshape(-1, k, c).contiguous()
+        w = weight.contiguous()
+        y = torch.empty((x2.shape[0], c * m), dtype=torch.float32, device=x.device)
+        check(_lib.lib().hf_depthwise_k(x2.shape[0], k, c, m, ptr(x2), ptr(w), ptr(y), stream_ptr()), "depthwise_k")
+        ctx.save_for_backward(x2, w)
+        ctx.lead = tuple(x.shape[:-2])
+        return y.reshape(*ctx.lead, c * m)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w = ctx.saved_tensors
+        k, c, m = w.shape
+        gy = gy.reshape(-1, c * m).contiguous()
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().hf_depthwise_k_grad(x2.shape[0], k, c, m, ptr(x2), ptr(w), ptr(gy), ptr(gx), ptr(gw), stream_ptr()),
+              "depthwise_k_grad")
+        return (gx.reshape(*ctx.lead, k, c) if gx is not None else None), gw
+
+
 def depthwise_k(x, weight):
     """x (.., K, C), weight (K, C, M) (TensorFlow's depthwise filter (1, K, C, M) without the unit height) -> (.., C*M):
-    a VALID depthwise convolution with a (1, K) window over a width-K input leaves one position, channel c*M + m"""
+    a VALID depthwise convolution with a (1, K) window over a width-K input leaves one position, channel c*M + m.
+    On the device with a supported (K, M): the HIP kernel; otherwise the einsum form (same values to fp32 rounding)."""
+    k, c, m = weight.shape
+    if _hip_ok(x, weight) and (k, m) in _DEPTHWISE_KM and x.shape[-2] == k and x.shape[-1] == c:
+        return _DepthwiseK.apply(x, weight)
     y = torch.einsum("...wc,wcm->...cm", x, weight)
     return y.reshape(*y.shape[:-2], -1)
+
+
+class _XApply(torch.autograd.Function):
+    """hf_xconv_apply / hf_xconv_apply_grad: F_X = X x F_* per representative point (pointcnn.py:133)"""
+
+    @staticmethod
+    def forward(ctx, x, f):
+        k, c = f.shape[-2], f.shape[-1]
+        x2 = x.reshape(-1, k, k).contiguous()
+        f2 = f.reshape(-1, k, c).contiguous()
+        out = torch.empty_like(f2)
+        check(_lib.lib().hf_xconv_apply(f2.shape[0], k, c, ptr(x2), ptr(f2), ptr(out), stream_ptr()), "xconv_apply")
+        ctx.save_for_backward(x2, f2)
+        ctx.shapes = (tuple(x.shape), tuple(f.shape))
+        return out.reshape(f.shape)
+
+    @staticmethod
+    def backward(ctx, go):
+        x2, f2 = ctx.saved_tensors
+        k, c = f2.shape[1], f2.shape[2]
+        go = go.reshape(-1, k, c).contiguous()
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gf = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().hf_xconv_apply_grad(f2.shape[0], k, c, ptr(x2), ptr(f2), ptr(go), ptr(gx), ptr(gf), stream_ptr()),
+              "xconv_apply_grad")
+        sx, sf = ctx.shapes
+        return (gx.reshape(sx) if gx is not None else None), (gf.reshape(sf) if gf is not None else None)
+
+
+def x_apply(x, f):
+    """x (.., K, K), f (.., K, C) -> (.., K, C) = x @ f"""
+    if _hip_ok(x, f) and f.shape[-2] in _XAPPLY_K and x.shape[-1] == x.shape[-2] == f.shape[-2]:
+        return _XApply.apply(x, f)
+    return torch.matmul(x, f)
 
 
 class DepthwiseK(nn.Module):
@@ -136,7 +210,7 @@ class XConv(nn.Module):
             x = self.x0(local.reshape(b, p, 1, k * 3)).reshape(b, p, k, k)
             x = self.x1(x).reshape(b, p, k, k)
             x = self.x2(x).reshape(b, p, k, k)
-            f = torch.matmul(x, f)                            # F_X <- X x F_*
+            f = x_apply(x, f)                                 # F_X <- X x F_*
         out = self.conv(f)                                    # (B,P,C)
         if self.with_global:
             out = torch.cat([self.g1(self.g0(qrs)), out], dim=-1)

@@ -341,6 +341,22 @@ int hf_bin_head_decode(long long rows, int k, int nbx, int nbz, int nbt, const f
                        const float *ref_theta, const float *mean_sizes_k, const float *ss, const float *deltas, float r,
                        float delta_theta, const int *cls, float *boxes, hf_stream_t stream);
 
+/* ------------------------------------------------------------------- PointCNN X-Conv products (callers)
+ * hf_xconv_apply       replaces tf.matmul(X, nn_fts_input)  hf/core/feature_extractors/pointcnn.py:133
+ *                      x (rows,k,k), f (rows,k,c) -> out (rows,k,c): out[r][i][:] = sum_j x[r][i][j] * f[r][j][:]; k in {4, 8}
+ * hf_xconv_apply_grad  its gradients: grad_x (rows,k,k) and / or grad_f (rows,k,c) (either may be NULL)
+ * hf_depthwise_k       replaces pf.depthwise_conv2d(.., (1,K)) and the depthwise half of pf.separable_conv2d(.., (1,K))
+ *                      on a width-K input (pointfly.py:437-457; pointcnn.py:104-131): x (rows,k,c), w (k,c,m) in
+ *                      TensorFlow's depthwise filter layout (1,K,C,M) -> y (rows, c*m), y[r][ch*m+mm] = sum_w x[r][w][ch]*w[w][ch][mm]
+ * hf_depthwise_k_grad  grad_x (rows,k,c) and / or grad_w (k,c,m) (zero-filled here, accumulated with atomics)
+ * (k, m) supported: k = 8 with m in {1,2,3,4,8}, k = 4 with m in {1,4}; anything else: HF_EINVAL. */
+int hf_xconv_apply(long long rows, int k, int c, const float *x, const float *f, float *out, hf_stream_t stream);
+int hf_xconv_apply_grad(long long rows, int k, int c, const float *x, const float *f, const float *grad_out, float *grad_x,
+                        float *grad_f, hf_stream_t stream);
+int hf_depthwise_k(long long rows, int k, int c, int m, const float *x, const float *w, float *y, hf_stream_t stream);
+int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float *x, const float *w, const float *grad_y,
+                        float *grad_x, float *grad_w, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,3 +123,44 @@ def test_rpn_multiclass_train_step_small():
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < 0.85 * losses[0], losses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,k,c", [(1, 8, 1), (37, 8, 65), (300, 8, 320), (5, 4, 7), (2048, 8, 1280)])
+def test_x_apply_kernel_against_matmul(rows, k, c):
+    """hf_xconv_apply (+ grad) = torch.matmul(X, F) and its autograd, fp32 (pointcnn.py:133)"""
+    from heterofusionrcnn_amd import pointcnn
+    g = torch.Generator().manual_seed(rows + c)
+    x = torch.randn(rows, k, k, generator=g).cuda().requires_grad_(True)
+    f = torch.randn(rows, k, c, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(rows, k, c, generator=g).cuda()
+    out = pointcnn.x_apply(x, f)
+    out.backward(go)
+    xr, fr = x.detach().double().requires_grad_(True), f.detach().double().requires_grad_(True)
+    ref = torch.matmul(xr, fr)
+    ref.backward(go.double())
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(f.grad.double(), fr.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-5, atol=1e-4 * max(1.0, c ** 0.5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,k,c,m", [(3, 8, 8, 8), (1000, 8, 8, 8), (77, 8, 65, 4), (500, 8, 320, 1), (129, 8, 640, 2), (9, 4, 5, 4)])
+def test_depthwise_k_kernel_against_conv2d(rows, k, c, m):
+    """hf_depthwise_k (+ grad) = tf.nn.depthwise_conv2d with a (1,K) window on a width-K input, channel c*M + m,
+    checked against torch's grouped conv2d with the same weights and its autograd in fp64"""
+    from heterofusionrcnn_amd import pointcnn
+    g = torch.Generator().manual_seed(rows * 7 + c + m)
+    x = torch.randn(rows, k, c, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(k, c, m, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(rows, c * m, generator=g).cuda()
+    y = pointcnn.depthwise_k(x, w)
+    y.backward(gy)
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    # NCHW: (rows, C, 1, K); grouped conv weight (C*M, 1, 1, K) with out channel c*M + m
+    ref = torch.nn.functional.conv2d(xr.permute(0, 2, 1).unsqueeze(2), wr.permute(1, 2, 0).reshape(c * m, 1, 1, k), groups=c)
+    ref = ref.reshape(rows, c * m)
+    ref.backward(gy.double())
+    assert torch.allclose(y.double(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(w.grad.double(), wr.grad, rtol=1e-4, atol=1e-4 * max(1.0, rows ** 0.5))
