@@ -32,7 +32,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .grouping import group_point, knn_point
 from .sampling import farthest_point_sample, gather_point
-from .mlp import BatchNormReLU
+from .mlp import BatchNormReLU, linear_nobias
 
 
 class EluBN(nn.Module):
@@ -61,7 +61,7 @@ class Dense(nn.Module):
         self.post = EluBN(cout, activation)
 
     def forward(self, x):
-        return self.post(self.linear(x))
+        return self.post(linear_nobias(x, self.linear.weight))
 
 
 _XAPPLY_K = (4, 8)                                             # K with a HIP kernel (csrc/xconv.hip); shipped configs: 8
@@ -169,7 +169,7 @@ class SeparableK(nn.Module):
         self.post = EluBN(cout, True)
 
     def forward(self, x):                                    # (B,P,K,Cin)
-        return self.post(self.pointwise(depthwise_k(x, self.depthwise)))
+        return self.post(linear_nobias(depthwise_k(x, self.depthwise), self.pointwise.weight))
 
 
 class XConv(nn.Module):

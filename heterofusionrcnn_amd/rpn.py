@@ -32,7 +32,7 @@ from .fusion import fuse_point_image_features, project_gather
 from .modules import PointnetFPModule, PointnetSAModule, SharedMLPLayer
 from .grouping import group_concat, group_point, query_ball_group
 from .sampling import farthest_point_sample, gather_point
-from .mlp import BatchNormReLU, shared_mlp
+from .mlp import BatchNormReLU, shared_mlp, linear_nobias
 
 
 # ------------------------------------------------------------------------------------------------ configuration
@@ -248,7 +248,7 @@ class DenseEluBN(nn.Module):
         self.activation = activation
 
     def forward(self, x):
-        y = self.linear(x)
+        y = linear_nobias(x, self.linear.weight)
         if self.activation:
             y = F.elu(y)
         return self.bn(y)
