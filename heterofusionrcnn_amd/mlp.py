@@ -79,6 +79,12 @@ class _LinearSplitK(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        rows, cin = x.shape
+        cout = weight.shape[0]
+        if _mfma_forward_pays(rows, cin, cout) and cout < 128:
+            # narrow outputs (the 76-value box head: 131 072 x 512 -> 76) leave the library at 15 TFLOP/s (650 us);
+            # the MFMA forward kernel streams x once (its statistics epilogue is simply not used)
+            return linear_bn_fwd(x, weight.contiguous(), _zeros(cout, x.device), _NO_BN, update_running=False)[0]
         return x @ weight.t()
 
     @staticmethod
@@ -88,6 +94,53 @@ class _LinearSplitK(torch.autograd.Function):
         dx = g @ weight if ctx.needs_input_grad[0] else None
         dw = _splitk_wgrad(g, x) if ctx.needs_input_grad[1] else None
         return dx, dw
+
+
+class _NoBN:
+    eps, momentum, running_mean, running_var = 1e-5, 0.0, None, None
+
+
+_NO_BN = _NoBN()
+_ZEROS = {}
+
+
+def _zeros(n, device):
+    key = (n, str(device))
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return _ZEROS[key]
+
+
+class _NarrowLinear(torch.autograd.Function):
+    """y = x W^T + b for a handful of outputs (the segmentation head: 256 -> 2).  The input gradient g W is a GEMM with
+    an inner dimension of 2, which the library runs at 490 us for 131 072 rows; written as Cout scaled additions it is
+    one streaming pass.  Weight gradient on the split-K path."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = g[:, 0:1] * weight[0]
+            for j in range(1, weight.shape[0]):
+                dx = torch.addcmul(dx, g[:, j:j + 1], weight[j])
+        dw = _splitk_wgrad(g, x) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear_narrow(x, weight, bias):
+    """x (.., Cin) -> (.., Cout) with Cout <= 4"""
+    if x.is_cuda and x.dtype == torch.float32 and weight.shape[0] <= 4 and x.numel() // x.shape[-1] >= 32768:
+        y = _NarrowLinear.apply(x.reshape(-1, x.shape[-1]).contiguous(), weight, bias)
+        return y.reshape(*x.shape[:-1], weight.shape[0])
+    return torch.nn.functional.linear(x, weight, bias)
 
 
 def linear_nobias(x, weight):

@@ -32,7 +32,7 @@ from .fusion import fuse_point_image_features, project_gather
 from .modules import PointnetFPModule, PointnetSAModule, SharedMLPLayer
 from .grouping import group_concat, group_point, query_ball_group
 from .sampling import farthest_point_sample, gather_point
-from .mlp import BatchNormReLU, shared_mlp, linear_nobias
+from .mlp import BatchNormReLU, shared_mlp, linear_nobias, linear_narrow
 
 
 # ------------------------------------------------------------------------------------------------ configuration
@@ -274,7 +274,7 @@ class RpnHeads(nn.Module):
 
     def forward(self, pc_fts, proj_img_fts=None):
         b, p, c = pc_fts.shape
-        seg_logits = self.seg(pc_fts)                              # (B,P,K+1)
+        seg_logits = linear_narrow(pc_fts, self.seg.weight, self.seg.bias)   # (B,P,K+1)
         x = pc_fts
         if self.cfg.fusion != "none":
             x = fuse_point_image_features(pc_fts, proj_img_fts, self.cfg.fusion)
