@@ -574,6 +574,20 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_op_table:
             result["extra"] = per_op_table(hf, xyz8)
+            if args.workload == "rpn":
+                # the other RPN configuration (rpn_multiclass.config: PointCNN backbone, three classes), measured by a CHILD
+                # process of this one after the timed region (same contract: barrier, K timed steps, one JSON line)
+                import subprocess
+                try:
+                    child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "rpn_multiclass", "--steps", "6",
+                                            "--warmup", "3", "--no-op-table", "--no-cpu-baseline"], capture_output=True, text=True,
+                                           timeout=300)
+                    line = [l for l in child.stdout.splitlines() if l.startswith("{")][-1]
+                    other = json.loads(line)
+                    result["extra"]["rpn_multiclass_train_step"] = {"frames_per_s": other["value"], "ms_per_step": other["ms_per_step"],
+                                                                    "workload": other["config"]["workload"]}
+                except Exception as e:   # the headline line must not depend on this side measurement
+                    result["extra"]["rpn_multiclass_train_step"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline:
             if levels is None:   # PointCNN: the CPU chain of the PointNet++ paper config is reported (same ops, other schedule)
                 pc = rpn_mod.rpn_cars_pointnet_paper()

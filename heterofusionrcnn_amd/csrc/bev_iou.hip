@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "hf_common.h"
 
@@ -347,38 +348,44 @@ __global__ __launch_bounds__(kIouThreads, 8) void bev_iou_kernel(int num_a, cons
             const float4 q = *reinterpret_cast<const float4 *>(&sh.cb[min(c0 + i, 63)]);
             bx[i >> 1][i & 1] = q.x; by[i >> 1][i & 1] = q.y; bs[i >> 1][i & 1] = q.z + 1e-3f + 1e-5f * q.w;
         }
-        // a wave covers four rows per step; the trip count is wave-uniform (the ballots below need every lane)
-        for (int rb = (t >> 6) * 4; rb < row_size; rb += kIouThreads / 16) {
-            const int g = (t >> 4) & 3, r = rb + g;
-            const bool live = r < row_size && c0 < col_size;
-            const float4 a = *reinterpret_cast<const float4 *>(&sh.ra[live ? r : 0]);   // cx, cy, rad, mag
-            const float as = a.z + 1e-5f * a.w;
-            unsigned m16[4];       // bit k = pair (r, 4 k + i) is far apart: the ballot bits of the 16 lanes of my row
-            unsigned surv = 0u;    // my pairs that go on to the next filter
+        // a wave covers four rows per step; the trip count is wave-uniform (the ballots below need every lane).  Full
+        // tiles (all of them when the matrix is a multiple of 80 x 64) run without the per-row / per-column validity masks.
+        auto filter_rows = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            for (int rb = (t >> 6) * 4; rb < row_size; rb += kIouThreads / 16) {
+                const int r = rb + ((t >> 4) & 3);
+                const bool live = FULL || (r < row_size && c0 < col_size);
+                const float4 a = *reinterpret_cast<const float4 *>(&sh.ra[live ? r : 0]);   // cx, cy, rad, mag
+                const float as = a.z + 1e-5f * a.w;
+                unsigned m16[4];       // bit k = pair (r, 4 k + i) is far apart: the ballot bits of the 16 lanes of my row
+                unsigned surv = 0u;    // my pairs that go on to the next filter
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // = circles_apart(): centres further apart than the radius bounds plus a slack that dwarfs MARGIN and
-                // fp32 rounding; NaN / inf compare false -> next filter
-                const f2v reach = bs[h] + as;
-                const f2v dx = bx[h] - a.x, dy = by[h] - a.y;
-                const f2v d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
-                const f2v r2 = reach * reach;
+                for (int h = 0; h < 2; ++h) {
+                    // = circles_apart(): centres further apart than the radius bounds plus a slack that dwarfs MARGIN and
+                    // fp32 rounding; NaN / inf compare false -> next filter
+                    const f2v reach = bs[h] + as;
+                    const f2v dx = bx[h] - a.x, dy = by[h] - a.y;
+                    const f2v d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+                    const f2v r2 = reach * reach;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = 2 * h + u;
-                    const bool in = live && c0 + i < col_size;
-                    const bool far = in && d2[u] > r2[u];
-                    if (in && !far) surv |= 1u << i;
-                    const unsigned long long bal = __ballot(far);
-                    const unsigned half = (t & 32) ? static_cast<unsigned>(bal >> 32) : static_cast<unsigned>(bal);
-                    m16[i] = (half >> (t & 16)) & 0xffffu;
+                    for (int u = 0; u < 2; ++u) {
+                        const int i = 2 * h + u;
+                        const bool in = FULL || (live && c0 + i < col_size);
+                        const bool far = in && d2[u] > r2[u];
+                        if (in && !far) surv |= 1u << i;
+                        const unsigned long long bal = __ballot(far);
+                        const unsigned half = (t & 32) ? static_cast<unsigned>(bal >> 32) : static_cast<unsigned>(bal);
+                        m16[i] = (half >> (t & 16)) & 0xffffu;
+                    }
                 }
+                for (; surv; surv &= surv - 1u)   // about one pair in a hundred
+                    sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | (c0 + __builtin_ctz(surv)));
+                if (live && (t & 15) == 0)
+                    sh.apart[r] = (static_cast<unsigned long long>(m16[2] | (m16[3] << 16)) << 32) | (m16[0] | (m16[1] << 16));
             }
-            for (; surv; surv &= surv - 1u)   // about one pair in a hundred
-                sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | (c0 + __builtin_ctz(surv)));
-            const unsigned long long word = (static_cast<unsigned long long>(m16[2] | (m16[3] << 16)) << 32) | (m16[0] | (m16[1] << 16));
-            if (live && (t & 15) == 0) sh.apart[r] = word;
-        }
+        };
+        if (row_size == kIouRows && col_size == 64) filter_rows(std::true_type{});
+        else filter_rows(std::false_type{});
     }
     __syncthreads();   // the only barrier after the staging: from here on the storing wave and the clipping waves part
     if (stop == 3) return;
