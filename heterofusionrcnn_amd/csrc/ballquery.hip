@@ -147,7 +147,7 @@ __device__ __forceinline__ void store_p3(__amdgpu_buffer_rsrc_t r, unsigned elem
     __builtin_amdgcn_raw_buffer_store_b96(v, r, static_cast<int>(elem * 12u), 0, StoreAux<SM>::value);
 }
 
-template <bool GROUP, int SM, int NT>
+template <bool GROUP, int SM, int NT, bool A4>
 __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int glog, float radius,
                                                                 float thresh, float inv_cs, int nsample,
                                                                 int ns_shift, int cap, int stop,
@@ -199,13 +199,33 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     // 64 bytes per clock is ~3000 cycles) while the bitmap is built; the second half follows the marking
     float px[kCellPPT], py[kCellPPT], pz[kCellPPT];
     constexpr int kEarly = kCellPPT / 2;
-    // points u0 .. u1-1 of this thread in the segment that starts at seg0 (k = seg0 + u * NT + t)
+    // points u0 .. u1-1 of this thread in the segment that starts at seg0.
+    // A4 (the cloud starts on a 16-byte boundary and n is a multiple of 4): slot u = point 4 (t + (u/4) NT) + u%4, i.e. a
+    // thread owns FOUR CONSECUTIVE points = 48 bytes = three aligned 16-byte loads (three texture-path requests for four
+    // points instead of four; scripts/probes/l2_read_probe.hip).  Otherwise slot u = point u NT + t, one 12-byte load each.
     auto load_points = [&](auto u0_tag, auto u1_tag, int seg0) {
         constexpr int U0 = decltype(u0_tag)::value, U1 = decltype(u1_tag)::value;
+        if constexpr (A4) {
+            static_assert(U0 % 4 == 0 && U1 % 4 == 0, "whole quads");
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int u = U0; u < U1; ++u) {
-            const P3 p = load_p3(rcloud, static_cast<unsigned>(seg0 + u * kCellThreads + t));   // past the end: zeros, masked out later
-            px[u] = p.x; py[u] = p.y; pz[u] = p.z;
+            for (int q = U0 / 4; q < U1 / 4; ++q) {
+                const int byte0 = (seg0 + 4 * (q * kCellThreads + t)) * 12;   // past the end: zeros, masked out later
+                const u4v a = __builtin_amdgcn_raw_buffer_load_b128(rcloud, byte0, 0, 0);
+                const u4v b = __builtin_amdgcn_raw_buffer_load_b128(rcloud, byte0 + 16, 0, 0);
+                const u4v c = __builtin_amdgcn_raw_buffer_load_b128(rcloud, byte0 + 32, 0, 0);
+                const int u = 4 * q;
+                px[u] = __uint_as_float(a.x); py[u] = __uint_as_float(a.y); pz[u] = __uint_as_float(a.z);
+                px[u + 1] = __uint_as_float(a.w); py[u + 1] = __uint_as_float(b.x); pz[u + 1] = __uint_as_float(b.y);
+                px[u + 2] = __uint_as_float(b.z); py[u + 2] = __uint_as_float(b.w); pz[u + 2] = __uint_as_float(c.x);
+                px[u + 3] = __uint_as_float(c.y); py[u + 3] = __uint_as_float(c.z); pz[u + 3] = __uint_as_float(c.w);
+            }
+        } else {
+#pragma unroll
+            for (int u = U0; u < U1; ++u) {
+                const P3 p = load_p3(rcloud, static_cast<unsigned>(seg0 + u * kCellThreads + t));   // past the end: zeros, masked out later
+                px[u] = p.x; py[u] = p.y; pz[u] = p.z;
+            }
         }
     };
 #ifndef HF_QBP_ORDER
@@ -278,8 +298,11 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     //   pass 1  bitmap lookups, four in flight, -> one mask bit per point (no divergence);
     //   slots   one LDS atomic per WAVE reserves the wave's candidate slots (DPP prefix of the lane counts);
     //   pass 2  every lane walks the set bits of its mask and records the data index in its slots.
-    auto add_points = [&](auto np_tag, const float *x, const float *y, const float *z, int k0, int lim) {
+    // quad_tag: slot u = point k0 + 4 (u/4) NT + u%4 (the A4 layout, k0 = seg0 + 4 t); else k0 + u NT (k0 = seg0 + t)
+    auto add_points = [&](auto np_tag, auto quad_tag, const float *x, const float *y, const float *z, int k0, int lim) {
         constexpr int NP = decltype(np_tag)::value;
+        constexpr bool QUAD = decltype(quad_tag)::value;
+        auto kof = [&](int u) -> int { return QUAD ? k0 + 4 * (u >> 2) * kCellThreads + (u & 3) : k0 + u * kCellThreads; };
         unsigned mask = 0u;
 #pragma unroll
         for (int u0 = 0; u0 < NP; u0 += 4) {
@@ -294,8 +317,9 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
         }
         HF_STAMP(14);
         if (exh) mask = NP >= 32 ? ~0u : (1u << (NP & 31)) - 1u;
-        // valid points: k0 + u * 1024 < lim
-        const int nvalid = lim > k0 ? min(NP, (lim - k0 + kCellThreads - 1) / kCellThreads) : 0;
+        // valid points: kof(u) < lim; in the quad layout lim is a multiple of 4, so quads are valid or not as a whole
+        const int nvalid = lim > k0 ? (QUAD ? min(NP, 4 * ((lim - k0 + 4 * kCellThreads - 1) / (4 * kCellThreads)))
+                                            : min(NP, (lim - k0 + kCellThreads - 1) / kCellThreads)) : 0;
         mask &= nvalid >= 32 ? ~0u : (1u << (nvalid & 31)) - 1u;
         const int mine = __builtin_popcount(mask);
         const int inc = wave_inclusive_scan_i32(mine);
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
                 if (mask) {
                     const int u = __builtin_ctz(mask);
                     mask &= mask - 1u;
-                    kk[i] = k0 + u * kCellThreads;
+                    kk[i] = kof(u);
                     pp[i] = load_p3(rcloud, static_cast<unsigned>(kk[i]));
                 }
             }
@@ -468,7 +492,7 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
             load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kCellPPT>{}, seg0);
             __syncthreads();
         }
-        add_points(std::integral_constant<int, kCellPPT>{}, px, py, pz, seg0 + t, n);
+        add_points(std::integral_constant<int, kCellPPT>{}, std::integral_constant<bool, A4>{}, px, py, pz, A4 ? seg0 + 4 * t : seg0 + t, n);
         HF_STAMP(4);
         __syncthreads();
         HF_STAMP(5);
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
                     cx[s] = p.x; cy[s] = p.y; cz[s] = p.z;
                 }
                 __syncthreads();
-                add_points(std::integral_constant<int, kCellChunkSlots>{}, cx, cy, cz, base + t, segend);
+                add_points(std::integral_constant<int, kCellChunkSlots>{}, std::false_type{}, cx, cy, cz, base + t, segend);
                 __syncthreads();
                 search();
                 nflush += 2;   // rows may refer to overwritten slots: step 6 reads the cloud
@@ -576,7 +600,7 @@ static int cell_env_int(const char *name, int dflt)
     return e && e[0] ? atoi(e) : dflt;
 }
 
-template <bool GRP, int SM, int NT>
+template <bool GRP, int SM, int NT, bool A4>
 static int cell_launch(dim3 grid, size_t lds, hipStream_t st, int n, int m, int qpw, int glog, float radius, float thresh,
                         float inv_cs, int nsample, int ns_shift, int cap, int stop, const float *xyz1, const float *xyz2,
                         int center, int *idx, int *pts_cnt, float *grouped)
@@ -585,16 +609,16 @@ static int cell_launch(dim3 grid, size_t lds, hipStream_t st, int n, int m, int 
     static int static_lds = -1;
     if (static_lds < 0) {
         hipFuncAttributes fa;
-        static_lds = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&qbp_cell_kernel<GRP, SM, NT>)) == hipSuccess
+        static_lds = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&qbp_cell_kernel<GRP, SM, NT, A4>)) == hipSuccess
                          ? static_cast<int>(fa.sharedSizeBytes) : 1;
     }
     if (static_lds != 0) return HF_EINVAL;   // lds_u32 assumes the dynamic region starts at LDS address 0
     if (lds > lds_allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_cell_kernel<GRP, SM, NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_cell_kernel<GRP, SM, NT, A4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         lds_allowed = 160 * 1024 - 512;
     }
-    hipLaunchKernelGGL((qbp_cell_kernel<GRP, SM, NT>), grid, dim3(NT), lds, st, n, m, qpw, glog, radius, thresh, inv_cs,
+    hipLaunchKernelGGL((qbp_cell_kernel<GRP, SM, NT, A4>), grid, dim3(NT), lds, st, n, m, qpw, glog, radius, thresh, inv_cs,
                        nsample, ns_shift, cap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped);
     return launch_status();
 }
@@ -624,11 +648,14 @@ int launch_ball_query_cell(int b, int n, int m, float radius, float thresh, int 
     int ns_shift = -1;
     if ((nsample & (nsample - 1)) == 0) { ns_shift = 0; while ((1 << ns_shift) < nsample) ++ns_shift; }
     dim3 grid(b, div_up(m, qpw));
+    // four consecutive points per thread through 16-byte loads when every cloud starts on a 16-byte boundary
+    // (HF_QBP_A4=0: diagnostics, the 12-byte form)
+    const bool a4 = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(xyz1) % 16 == 0) && cell_env_int("HF_QBP_A4", 1) != 0;
 #define HF_CELL_ARGS grid, lds, st, n, m, qpw, glog, radius, thresh, inv_cs, nsample, ns_shift, cap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped
 #define HF_CELL_DISPATCH(GRP, SMODE)                                                                                   \
     do {                                                                                                              \
-        if (nt == 1024) return cell_launch<GRP, SMODE, 1024>(HF_CELL_ARGS);                                           \
-        else return cell_launch<GRP, SMODE, 512>(HF_CELL_ARGS);                                                       \
+        if (nt == 1024) return a4 ? cell_launch<GRP, SMODE, 1024, true>(HF_CELL_ARGS) : cell_launch<GRP, SMODE, 1024, false>(HF_CELL_ARGS); \
+        else return cell_launch<GRP, SMODE, 512, false>(HF_CELL_ARGS);                                                \
     } while (0)
     if (grouped) {
         if (sm == 0) HF_CELL_DISPATCH(true, 0);

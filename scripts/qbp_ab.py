@@ -41,10 +41,10 @@ for B in (8, 80):
     a_fused = (B, 16384, m, R, K, xyz.data_ptr(), new_xyz.data_ptr(), 1, idx.data_ptr(), cnt.data_ptr(), grouped.data_ptr(), st)
     a_qbp = (B, 16384, m, R, K, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), cnt.data_ptr(), st)
     ref = None
-    for name, env in (("cell512_nt", {"HF_QBP_NT": "512"}),
+    for name, env in (("cell_b96_nt", {"HF_QBP_A4": "0"}), ("cell512_nt", {"HF_QBP_NT": "512"}),
                       ("cell_plain", {"HF_QBP_STORE": "0"}), ("cell_nt", {"HF_QBP_STORE": "1"}),
                       ("cell_wt", {"HF_QBP_STORE": "2"})):
-        for k in ("HF_BALL_QUERY", "HF_QBP_STORE", "HF_QBP_NT"):
+        for k in ("HF_BALL_QUERY", "HF_QBP_STORE", "HF_QBP_NT", "HF_QBP_A4"):
             os.environ.pop(k, None)
         os.environ.update(env)
         idx.fill_(-7); cnt.fill_(-7); grouped.fill_(-7.0)
@@ -61,7 +61,7 @@ for B in (8, 80):
     if B == 8:
         o_idx, o_cnt = oracle.query_ball_point(R, K, xyz[:1].cpu().numpy(), new_xyz[:1].cpu().numpy())
         assert np.array_equal(ref[0][:1].cpu().numpy(), o_idx) and np.array_equal(ref[1][:1].cpu().numpy(), o_cnt)
-        for k in ("HF_BALL_QUERY", "HF_QBP_STORE", "HF_QBP_NT"):
+        for k in ("HF_BALL_QUERY", "HF_QBP_STORE", "HF_QBP_NT", "HF_QBP_A4"):
             os.environ.pop(k, None)
         if os.environ.get("PHASES"):
             os.environ["HF_QBP_STORE"] = os.environ.get("PHASE_STORE", "0")
