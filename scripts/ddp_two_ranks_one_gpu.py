@@ -3,7 +3,9 @@ nodes under DistributedDataParallel.  Each rank trains on its own frames; after 
 updated weights must equal a single-process run over both shards (mean of the two per-shard gradients), and both ranks
 must hold identical weights.  RCCL itself needs one GPU per rank; this exercises everything else of the N > 1 path
 (DDP hooks on the fused nodes, zero bias gradients, grouped geometry prefetch) on the 1-GPU box.
-Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P scripts/ddp_two_ranks_one_gpu.py"""
+Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P scripts/ddp_two_ranks_one_gpu.py [rpn_multiclass]
+With the argument `rpn_multiclass` the model is the RPN of hf/configs/rpn_multiclass.config (PointCNN backbone, heads, targets,
+losses: BASELINE config 4), one 16384-point frame per rank."""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +13,7 @@ from heterofusionrcnn_amd import modules
 from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
 from bench import kitti_uniform
 
+WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "stack"
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -18,15 +21,39 @@ SA = ((512, 1.0, 16, (16, 32)), (128, 2.0, 16, (32, 64)))
 FP = ((64, 64), (32, 32))
 
 
+if WORKLOAD == "rpn_multiclass":
+    from heterofusionrcnn_amd import rpn as rpn_mod
+    CFG = rpn_mod.rpn_multiclass()
+
+
 def make():
     torch.manual_seed(11)
+    if WORKLOAD == "rpn_multiclass":
+        return rpn_mod.RpnModel(CFG).cuda()
     return modules.PointnetSAFPStack(in_channel=1, sa=SA, fp=FP).cuda()
 
 
 def batch(r):
     rng = np.random.default_rng(100 + r)
+    if WORKLOAD == "rpn_multiclass":
+        xyz = torch.from_numpy(kitti_uniform(rng, 1, 16384)).cuda()
+        inten = torch.from_numpy(rng.uniform(-.5, .5, (1, 16384, 1)).astype(np.float32)).cuda()
+        gt_boxes, gt_cls = rpn_mod.synthetic_ground_truth(rng, 1, 12, CFG, ground_y=3.0)
+        lc, lr = rpn_mod.point_labels(xyz, torch.from_numpy(gt_boxes).cuda(), torch.from_numpy(gt_cls).cuda())
+        return xyz, inten, lc, lr
     return (torch.from_numpy(kitti_uniform(rng, 2, 4096)).cuda(),
             torch.from_numpy(rng.uniform(-.5, .5, (2, 4096, 1)).astype(np.float32)).cuda())
+
+
+def loss_of(net, core, b, r, geometry=None):
+    """the scalar the step differentiates; the dropout masks of shard r are fixed by the seed"""
+    torch.manual_seed(1000 + r)
+    torch.cuda.manual_seed(1000 + r)
+    if WORKLOAD == "rpn_multiclass":
+        xyz, inten, lc, lr = b
+        seg_logits, head = net(xyz, inten, geometry=geometry)
+        return core.loss(xyz, seg_logits, head, lc, lr)[0]
+    return net(b[0], b[1], geometry=geometry).mean()
 
 
 model = make()
@@ -36,11 +63,11 @@ if rank == 1:                       # de-synchronise on purpose: DDP must broadc
             p.add_(0.5)
 net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
 opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
-xyz, inten = batch(rank)
+mine = batch(rank)
 pf = GeometryPrefetcher(model.geometry, depth=2, group=1)
-pf.submit(xyz)
+pf.submit(mine[0])
 opt.zero_grad(set_to_none=True)
-net(xyz, inten, geometry=pf.get()).mean().backward()
+loss_of(net, model, mine, rank, geometry=pf.get()).backward()
 grads = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
 opt.step()
 weights = torch.cat([p.detach().flatten() for p in model.parameters()])
@@ -53,13 +80,13 @@ if rank == 0:
     per = []
     for r in range(world):          # single process: the mean of the per-shard gradients
         ref.zero_grad(set_to_none=True)
-        ref(*batch(r)).mean().backward()
+        loss_of(ref, ref, batch(r), r).backward()
         per.append(torch.cat([p.grad.flatten() for p in ref.parameters()]).clone())
     want = (per[0] + per[1]) / 2
     # a pre-activation within rounding of zero may fall on the other side of the ReLU (see the chain test): relative bound
     err = (grads - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
     print("max relative gradient difference vs single process: %.3e" % err)
-    ok = err < 2e-3 and bool(torch.isfinite(weights).all())
+    ok = err < (2e-2 if WORKLOAD == "rpn_multiclass" else 2e-3) and bool(torch.isfinite(weights).all())
     print("TWO_RANK_OK" if ok else "TWO_RANK_FAIL")
 dist.barrier()
 dist.destroy_process_group()

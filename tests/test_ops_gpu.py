@@ -1367,15 +1367,17 @@ def test_two_stage_with_image_fusion_branch(hf):
         fuse_point_image_features(a, b, "max")
 
 
-def test_two_ddp_ranks_on_one_gpu(hf):
+@pytest.mark.parametrize("workload", ["stack", "rpn_multiclass"])
+def test_two_ddp_ranks_on_one_gpu(hf, workload):
     """scripts/ddp_two_ranks_one_gpu.py: two DistributedDataParallel ranks (gloo) sharing this GPU train the SA/FP
-    stack with its fused nodes for one step; gradients equal the mean of the per-shard gradients of a single process"""
+    stack with its fused nodes -- or the RPN of rpn_multiclass.config (PointCNN backbone, heads, losses: BASELINE
+    config 4) -- for one step; gradients equal the mean of the per-shard gradients of a single process"""
     import socket, subprocess, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(ROOT, "scripts", "ddp_two_ranks_one_gpu.py")],
+                          os.path.join(ROOT, "scripts", "ddp_two_ranks_one_gpu.py"), workload],
                          capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0 and "TWO_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
