@@ -228,11 +228,6 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
             }
         }
     };
-#ifndef HF_QBP_ORDER
-#define HF_QBP_ORDER 0
-#endif
-    if (HF_QBP_ORDER == 1) load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kCellPPT>{}, 0);
-    if (HF_QBP_ORDER == 3) load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kEarly>{}, 0);
     HF_STAMP(9);
     {
         typedef int i4 __attribute__((ext_vector_type(4)));
@@ -243,7 +238,7 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     HF_STAMP(10);
     __syncthreads();
     // the cloud requests go out behind the barrier: the query's latency is covered by issuing them
-    if (HF_QBP_ORDER == 0) load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kEarly>{}, 0);
+    load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kEarly>{}, 0);
     HF_STAMP(1);
 
     // cell of v along one axis = round(v / cs), read off the mantissa of fma(v, 1/cs, 1.5 * 2^23): one instruction,
@@ -285,8 +280,7 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     HF_STAMP(3);
     if (stop == -2) return;
     const bool exh = sh.exh != 0;   // uniform
-    if (HF_QBP_ORDER == 0 || HF_QBP_ORDER == 3) load_points(std::integral_constant<int, kEarly>{}, std::integral_constant<int, kCellPPT>{}, 0);
-    if (HF_QBP_ORDER == 2) load_points(std::integral_constant<int, 0>{}, std::integral_constant<int, kCellPPT>{}, 0);
+    load_points(std::integral_constant<int, kEarly>{}, std::integral_constant<int, kCellPPT>{}, 0);
 
     // key of the cell of a point: the raw float bits go into the multiply-adds (24-bit operands; only bits 0..12 of the
     // result are used and those depend on the low 13 bits of the operands alone); cx = raw bits of the x cell
