@@ -118,6 +118,36 @@ def time_op_stats(fn, iters=30, warm=5):
             "p90": round(float(np.percentile(us, 90)), 2)}
 
 
+def batched_kernel_burst(hf, clouds=80, launches=100):
+    """the same kernel on the batched shape the train step launches it with (the clouds of a geometry group in one launch),
+    alone on the device: per-cloud cost and fraction of the roofline when the fixed launch cost is amortised"""
+    from heterofusionrcnn_amd import _lib
+    L = _lib.lib()
+    m = SA[0][0]
+    xyz = torch.from_numpy(kitti_uniform(np.random.default_rng(2000), clouds, N0)).cuda()
+    new_xyz = hf.gather_point(xyz, hf.farthest_point_sample(m, xyz))
+    idx = torch.empty((clouds, m, KNN), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((clouds, m), dtype=torch.int32, device="cuda")
+    grouped = torch.empty((clouds, m, KNN, 3), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    args = (clouds, N0, m, SA[0][1], KNN, xyz.data_ptr(), new_xyz.data_ptr(), 1, idx.data_ptr(), cnt.data_ptr(),
+            grouped.data_ptr(), st)
+    for _ in range(5):
+        assert L.hf_query_ball_group_xyz(*args) == 0
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        L.hf_query_ball_group_xyz(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / launches
+    nbytes = SURVEY_TWO_OP_BYTES * clouds / B
+    return {"clouds_per_launch": clouds, "avg_launch_us": round(us, 2), "us_per_cloud": round(us / clouds, 3),
+            "achieved_GBs": round(nbytes / (us * 1e-6) / 1e9, 1), "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def headline_kernel_burst(hf, xyz, launches=200):
     """The roofline kernel alone on the device: `launches` back-to-back launches of hf_query_ball_group_xyz at
     the headline shape straight through the C ABI (outputs preallocated, nothing else in flight), bracketed by
@@ -569,7 +599,9 @@ def main():
                          "launches_timed": n_burst,
                          "in_step_avg_launch_us": round(in_step_us, 3) if in_step_us else None,
                          "in_step_launches": len(timer.pairs),
-                         "in_step_clouds_per_launch": per_gpu * (prefetch.group if prefetch is not None else 1)},
+                         "in_step_clouds_per_launch": per_gpu * (prefetch.group if prefetch is not None else 1),
+                         # the geometry-group shape launched alone (in the step it shares the device with the main stream)
+                         "batched_alone": batched_kernel_burst(hf) if world == 1 else None},
         }
     if rank == 0 and world == 1:
         if not args.no_op_table:

@@ -171,7 +171,8 @@ def _tf_running_var(torch_bn, rows):
 
 # ------------------------------------------------------------------ oracle, seeded inputs, ragged shapes
 @pytest.mark.parametrize("b,n,m,r,ns", [(2, 1024, 256, 0.12, 32), (3, 1000, 77, 0.2, 16), (1, 5000, 300, 0.08, 64),
-                                        (2, 300, 513, 0.5, 7), (1, 64, 1, 10.0, 128), (1, 3000, 5000, 0.15, 16), (1, 2000, 9000, 0.2, 8)])
+                                        (2, 300, 513, 0.5, 7), (1, 64, 1, 10.0, 128), (1, 3000, 5000, 0.15, 16), (1, 2000, 9000, 0.2, 8),
+                                        (40, 2048, 2000, 0.06, 32)])   # the last: 256 queries per workgroup (batched launches)
 def test_oracle_ball_query(hf, oracle_mod, b, n, m, r, ns):
     rng = np.random.default_rng(b * 1000 + n)
     x1 = rng.random((b, n, 3), dtype=np.float32)
