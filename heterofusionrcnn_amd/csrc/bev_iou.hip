@@ -89,6 +89,8 @@ struct __attribute__((aligned(16))) BoxPre {
     float pad_;
 };
 
+static_assert(sizeof(BoxPre) == 80, "the NMS workspace table and its 16-byte copies assume 80 bytes per box");
+
 __device__ __forceinline__ void box_precompute(const float *b, BoxPre &o)
 {
 #pragma unroll
@@ -494,15 +496,31 @@ struct __attribute__((aligned(16))) NmsEntry {
 constexpr int kNmsListCap = 2048;   // entries per column block (a column that overflows is swept from the dense mask)
 
 // per-frame workspace of hf_oriented_nms:
-// [mask n*cb words][counts cb ints, padded][lists cb * kNmsListCap entries][transposed diagonal words, n]
+// [mask n*cb words][counts cb ints, padded][lists cb * kNmsListCap entries][transposed diagonal words, n][BoxPre table, n]
 __host__ __device__ inline size_t nms_ws_counts_offset(int n) { return (sizeof(unsigned long long) * static_cast<size_t>(n) * ((n + 63) / 64) + 255) & ~static_cast<size_t>(255); }
 __host__ __device__ inline size_t nms_ws_lists_offset(int n) { return nms_ws_counts_offset(n) + ((sizeof(int) * static_cast<size_t>((n + 63) / 64) + 255) & ~static_cast<size_t>(255)); }
 __host__ __device__ inline size_t nms_ws_diagt_offset(int n) { return nms_ws_lists_offset(n) + sizeof(NmsEntry) * static_cast<size_t>((n + 63) / 64) * kNmsListCap; }
-__host__ __device__ inline size_t nms_ws_bytes(int n) { return nms_ws_diagt_offset(n) + ((sizeof(unsigned long long) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255)); }
+__host__ __device__ inline size_t nms_ws_boxpre_offset(int n) { return nms_ws_diagt_offset(n) + ((sizeof(unsigned long long) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255)); }
+__host__ __device__ inline size_t nms_ws_bytes(int n) { return nms_ws_boxpre_offset(n) + ((sizeof(BoxPre) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255)); }
 
 // UPPER_ONLY = the form hf_oriented_nms launches: `mask` is the frame-0 workspace (stride ws_stride bytes per frame),
 // tiles below the diagonal are skipped, and every nonzero word right of the diagonal is also appended to the list of
 // its column block.
+// the per-box part of the tile kernels once per box (hf_oriented_nms: 10 011 tiles at 9000 boxes would each redo the
+// cos / sin / corners of their 128 boxes)
+__global__ __launch_bounds__(256) void nms_boxpre_kernel(int n, const float *__restrict__ boxes, unsigned char *__restrict__ ws,
+                                                         size_t ws_stride)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    boxes += static_cast<size_t>(blockIdx.y) * n * 5;
+    BoxPre *table = reinterpret_cast<BoxPre *>(ws + static_cast<size_t>(blockIdx.y) * ws_stride + nms_ws_boxpre_offset(n));
+    BoxPre p;
+    box_precompute(boxes + static_cast<size_t>(i) * 5, p);
+    p.pad_ = 0.f;
+    table[i] = p;
+}
+
 template <bool UPPER_ONLY>
 __global__ __launch_bounds__(kNmsThreads, 4) void nms_mask_kernel(int n, float thresh, const float *__restrict__ boxes,
                                                                unsigned long long *__restrict__ mask, size_t ws_stride)
@@ -517,12 +535,44 @@ __global__ __launch_bounds__(kNmsThreads, 4) void nms_mask_kernel(int n, float t
     TileShared &sh = *reinterpret_cast<TileShared *>(smem_raw);
     const int t = threadIdx.x;
     const int row_size = min(n - row_t * 64, 64), col_size = min(n - col_t * 64, 64);
-    tile_stage(sh, boxes, row_t * 64, row_size, boxes, col_t * 64, col_size);
+    if (UPPER_ONLY) {
+        // the boxes' precomputed parts come from the table (80 bytes per box, copied 16 bytes per thread and step)
+        const float4 *table = reinterpret_cast<const float4 *>(ws + nms_ws_boxpre_offset(n));
+        constexpr int kVec = sizeof(BoxPre) / 16;
+        float4 *dst_c = reinterpret_cast<float4 *>(sh.cb), *dst_r = reinterpret_cast<float4 *>(sh.ra);
+        for (int i = t; i < col_size * kVec; i += kNmsThreads) dst_c[i] = table[static_cast<size_t>(col_t) * 64 * kVec + i];
+        for (int i = t; i < row_size * kVec; i += kNmsThreads) dst_r[i] = table[static_cast<size_t>(row_t) * 64 * kVec + i];
+        if (t < 64) sh.words[t] = 0ull;
+        if (t == kNmsThreads - 1) { sh.qcount = 0; sh.q2count = 0; sh.arrived = 0; }
+    } else {
+        tile_stage(sh, boxes, row_t * 64, row_size, boxes, col_t * 64, col_size);
+    }
     __syncthreads();
-    for (int e = t; e < 64 * 64; e += kNmsThreads) {
-        const int r = e >> 6, c = e & 63;
-        const bool valid = r < row_size && c < col_size && !(row_t == col_t && c <= r);
-        if (valid && !circles_apart(sh.ra[r], sh.cb[c])) sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>(e);
+    // filter 1: bounding circles, four fixed columns per thread in registers (as in bev_iou_kernel), rows 16 apart
+    {
+        const int c0 = (t & 15) * 4;
+        float bx[4], by[4], bs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 q = *reinterpret_cast<const float4 *>(&sh.cb[min(c0 + i, 63)]);
+            bx[i] = q.x; by[i] = q.y; bs[i] = q.z + 1e-3f + 1e-5f * q.w;
+        }
+        if (c0 < col_size) {
+            for (int r = t >> 4; r < row_size; r += kNmsThreads / 16) {
+                const float4 a = *reinterpret_cast<const float4 *>(&sh.ra[r]);   // cx, cy, rad, mag
+                const float as = a.z + 1e-5f * a.w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + i;
+                    const float reach = bs[i] + as;
+                    const float dx = bx[i] - a.x, dy = by[i] - a.y;
+                    const bool valid = c < col_size && !(row_t == col_t && c <= r);
+                    // NaN / inf compare false -> next filter
+                    if (valid && !(dx * dx + dy * dy > reach * reach))
+                        sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | c);
+                }
+            }
+        }
     }
     __syncthreads();
     const int nq = sh.qcount;
@@ -783,6 +833,7 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
     // the list counters start at zero (one strided memset: they sit at the same offset of every frame's workspace)
     int rc = hip_status(hipMemset2DAsync(ws + nms_ws_counts_offset(n), ws_stride, 0, sizeof(int) * static_cast<size_t>(cb), frames, st));
     if (rc != HF_OK) return rc;
+    hipLaunchKernelGGL(nms_boxpre_kernel, dim3(div_up(n, 256), frames), dim3(256), 0, st, n, boxes, ws, ws_stride);
     tile_lds_attr(&nms_mask_kernel<true>);
     hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(cb, cb, frames), dim3(kNmsThreads), sizeof(TileShared), st, n, thresh, boxes,
                        reinterpret_cast<unsigned long long *>(ws), ws_stride);
