@@ -288,13 +288,24 @@ struct TileSharedT {
     int qcount, q2count, arrived;
 };
 typedef TileSharedT<64, kTileThreads> TileShared;   // the square tiles of the NMS mask
-// compute_bev_iou: 80 x 64 tiles, 512 threads (38 KB of LDS, <= 64 VGPRs: four workgroups per CU).  70 000 rows are 875 workgroups =
-// ONE round of the 1024 resident slots (64-row tiles were 1094 workgroups, and the 70 of the second round doubled the
-// kernel's duration).  Waves 0..4 clip (40 groups of eight lanes: one pass for almost every tile), waves 5..7 write the zeros.
-constexpr int kIouRows = 80;
-constexpr int kIouThreads = 512;
-constexpr int kIouStoreWaves = 3;   // a wave keeps only a handful of stores in flight: one storing wave per workgroup drains
-                                    // the zeros at 4 TB/s, two at 5
+// compute_bev_iou: 96 x 64 tiles, 512 threads (46 KB of LDS, <= 64 VGPRs: three workgroups per CU).  70 000 rows are 730
+// workgroups = ONE round of the 768 resident slots (64-row tiles were 1094 workgroups, and the 70 of the second round
+// doubled the kernel's duration), and 96 rows are exactly three steps of the circle filter (measured in one run,
+// scripts/probes/bev_variant.py: 64 / 72 / 80 / 96 / 104 / 112 / 128 rows = 15.6 / 15.5 / 15.6 / 14.0 / 15.1 / 15.7 / 19.2 us).  Waves 0..5 clip (48 groups of eight lanes: one pass for almost every tile), waves 6..7 write the zeros
+// (measured in one run, scripts/probes/bev_variant.py: 1 / 2 / 3 / 4 storing waves = 18.8 / 15.7 / 17.1 / 17.7 us).
+#ifndef HF_IOU_ROWS
+#define HF_IOU_ROWS 96
+#endif
+constexpr int kIouRows = HF_IOU_ROWS;
+#ifndef HF_IOU_THREADS
+#define HF_IOU_THREADS 512
+#endif
+constexpr int kIouThreads = HF_IOU_THREADS;
+#ifndef HF_IOU_STORE_WAVES
+#define HF_IOU_STORE_WAVES 2
+#endif
+constexpr int kIouStoreWaves = HF_IOU_STORE_WAVES;   // a wave keeps only a handful of stores in flight: one storing wave per
+                                                      // workgroup drains the zeros at 4 TB/s, two at 5
 constexpr int kIouClipThreads = kIouThreads - 64 * kIouStoreWaves;
 typedef TileSharedT<kIouRows, kIouThreads> IouShared;
 
@@ -316,7 +327,7 @@ __device__ __forceinline__ void tile_stage(TileSharedT<ROWS, THREADS> &sh, const
     if (t == THREADS - 1) { sh.qcount = 0; sh.q2count = 0; sh.arrived = 0; }
 }
 
-// IoU matrix: one workgroup per 80 x 64 tile of (a, b) pairs.
+// IoU matrix: one workgroup per 96 x 64 tile of (a, b) pairs.
 // 99 % of the pairs are exact zeros by the first filter, and writing them (8 bytes per pair, both outputs) is the floor of
 // the kernel: ~6 us of store drain at 70 000 x 64.  A wave that issues those stores is held by the back-pressure of the
 // write path for that long -- so ONE wave (the last) issues them all, after the filters, while the other five clip the
@@ -354,6 +365,9 @@ __global__ __launch_bounds__(kIouThreads, 8) void bev_iou_kernel(int num_a, cons
         // tiles (all of them when the matrix is a multiple of 80 x 64) run without the per-row / per-column validity masks.
         auto filter_rows = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
+            static_assert((kIouRows + kIouThreads / 16 - 1) / (kIouThreads / 16) <= 8, "four bits per row step in one register");
+            unsigned surv_all = 0u;   // my pairs that go on to the next filter: four bits per row step
+            int iter = 0;
             for (int rb = (t >> 6) * 4; rb < row_size; rb += kIouThreads / 16) {
                 const int r = rb + ((t >> 4) & 3);
                 const bool live = FULL || (r < row_size && c0 < col_size);
@@ -380,10 +394,16 @@ __global__ __launch_bounds__(kIouThreads, 8) void bev_iou_kernel(int num_a, cons
                         m16[i] = (half >> (t & 16)) & 0xffffu;
                     }
                 }
-                for (; surv; surv &= surv - 1u)   // about one pair in a hundred
-                    sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | (c0 + __builtin_ctz(surv)));
+                surv_all |= surv << (4 * iter);
+                ++iter;
                 if (live && (t & 15) == 0)
                     sh.apart[r] = (static_cast<unsigned long long>(m16[2] | (m16[3] << 16)) << 32) | (m16[0] | (m16[1] << 16));
+            }
+            // the survivors of all my rows in one go (about one pair in a hundred): one trip to the queue counter per wave
+            for (; surv_all; surv_all &= surv_all - 1u) {
+                const int b = __builtin_ctz(surv_all);
+                const int r = (t >> 6) * 4 + (kIouThreads / 16) * (b >> 2) + ((t >> 4) & 3);
+                sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | (c0 + (b & 3)));
             }
         };
         if (row_size == kIouRows && col_size == 64) filter_rows(std::true_type{});
