@@ -16,7 +16,7 @@ def avg(d, counter, kernel="qbp_cell"):
 fetch, nf, ff = avg(sys.argv[1], "FETCH_SIZE")
 write, nw, fw = avg(sys.argv[2], "WRITE_SIZE")
 traffic = int(round((2.0 * fetch + write) * 1024))
-out = {"kernel": "hf::qbp_cell_kernel<true, 1, 1024, true> (hf_query_ball_group_xyz), B=8 N=16384 M=4096 K=32",
+out = {"kernel": "hf::qbp_cell_kernel<true, 2, 1024, true> (hf_query_ball_group_xyz), B=8 N=16384 M=4096 K=32",
        "kernel_source_stamp": kernel_source_stamp(),
        "FETCH_SIZE_KiB_per_launch": round(fetch, 1), "WRITE_SIZE_KiB_per_launch": round(write, 1),
        "launches": [nf, nw],
