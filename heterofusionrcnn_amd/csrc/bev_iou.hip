@@ -272,7 +272,6 @@ __device__ __forceinline__ float iou_from_overlap(const float *a, const float *b
 }
 
 // ---------------------------------------------------------------- 64 x 64 pair tiles
-constexpr int kTileThreads = 256;
 
 template <int ROWS, int THREADS>
 struct TileSharedT {
@@ -287,7 +286,10 @@ struct TileSharedT {
     unsigned long long late[ROWS];                 // IoU: the same for the zeros of the separating-axis filter
     int qcount, q2count, arrived;
 };
-typedef TileSharedT<64, kTileThreads> TileShared;   // the square tiles of the NMS mask
+#ifndef HF_NMS_THREADS
+#define HF_NMS_THREADS 512   // 256 / 384 / 512 / 768 threads: 9000 clustered boxes 317 / 281 / 257 / 267 us, uniform 180 / 190 / 183 / 231 us
+#endif
+typedef TileSharedT<64, HF_NMS_THREADS> TileShared;   // the square tiles of the NMS mask
 // compute_bev_iou: 96 x 64 tiles, 512 threads (46 KB of LDS, <= 64 VGPRs: three workgroups per CU).  70 000 rows are 730
 // workgroups = ONE round of the 768 resident slots (64-row tiles were 1094 workgroups, and the 70 of the second round
 // doubled the kernel's duration), and 96 rows are exactly three steps of the circle filter (measured in one run,
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(kIouThreads, 8) void bev_iou_kernel(int num_a, cons
 // ---------------------------------------------------------------- NMS mask
 // one block per (row tile, col tile) of 64x64 pairs; mask word (row, col tile) bit j set iff
 // iou(row, col*64+j) > thresh, j > row inside the diagonal tile (bev_iou_g.cu:256-298).
-constexpr int kNmsThreads = kTileThreads;
+constexpr int kNmsThreads = HF_NMS_THREADS;
 
 // An entry of a column block's list: a nonzero mask word right of the diagonal and the row it belongs to.
 struct __attribute__((aligned(16))) NmsEntry {
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(256) void nms_boxpre_kernel(int n, const float *__r
 }
 
 template <bool UPPER_ONLY>
-__global__ __launch_bounds__(kNmsThreads, 4) void nms_mask_kernel(int n, float thresh, const float *__restrict__ boxes,
+__global__ __launch_bounds__(kNmsThreads, HF_NMS_THREADS >= 512 ? 8 : 4) void nms_mask_kernel(int n, float thresh, const float *__restrict__ boxes,
                                                                unsigned long long *__restrict__ mask, size_t ws_stride)
 {
     const int row_t = blockIdx.y, col_t = blockIdx.x;
