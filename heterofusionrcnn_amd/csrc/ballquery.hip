@@ -13,11 +13,11 @@
 // query index, so every output of the workgroup (idx rows, grouped rows, counts) is one contiguous range.
 // Space is cut into cubic cells of width cs = 2.2 radius in a FIXED frame: cell(v) = round(v / cs) per axis, read off
 // the mantissa of one fma (no bounding box, no data-dependent grid: nothing to reduce before the first useful
-// instruction).  A cell is hashed to one of 65536 bits: word = (cy + A cx + B cz) mod 2048, bit = cx mod 32
+// instruction).  A cell is hashed to one of 131072 bits: word = (cy + A cx + B cz) mod 4096, bit = cx mod 32
 // (8 VALU instructions per point: 3 fma, 2 mad_u24, 1 and, the LDS read, 1 bfe, 1 merge).  The workgroup
 //   1  loads its queries, clears the bitmap and the list heads, and requests the cloud (16 points per thread stay
 //      in registers);
-//   2  marks, in a 8 KB bitmap in LDS, the <= 8 cells that each query's padded box [q - rp, q + rp] touches
+//   2  marks, in a 16 KB bitmap in LDS, the <= 8 cells that each query's padded box [q - rp, q + rp] touches
 //      (rp > radius; cs >= 2 rp, so <= 2 cells per axis);
 //   3  tests every point of the cloud against the bitmap (one 4-byte LDS read per point): a point whose bit is
 //      clear cannot be a hit of any of these queries (cell() is monotone, so a point inside a query's padded box
@@ -48,12 +48,13 @@
 namespace hf {
 
 constexpr int kCellSegPoints = 16384;   // points per register segment: NT threads hold 16384 / NT points each
-constexpr int kCellWords = 2048;        // bitmap words: 65536 hashed cells
+constexpr int kCellWords = 4096;        // bitmap words, 32 hashed cells each (2048 / 4096 / 8192 words: 69.4 / 66.7 / 67.8 us at 80 clouds,
+                                        // 10.8 / 10.8 / 10.9 us at 8)
 constexpr int kCellHeads = 4096;        // list heads, direct-mapped by 12 hash bits
-// key = 4 (cy + A cx + B cz) + (quarter-cell fraction of y): bits 2..12 = bitmap word, the bit in the word = cx mod 32
+// key = 4 (cy + A cx + B cz) + (quarter-cell fraction of y): bits 2..13 = bitmap word, the bit in the word = cx mod 32
 // (x is a long axis of a LiDAR scene in the camera frame and in the sensor frame alike; A, B: fewest false candidates
 // on KITTI-sized scenes at radii 0.1 .. 2 in both frames, as good as a full 16-bit multiplicative hash).
-// List head = that word index | (cx & 1) << 11.  The 8 cells of a query never share a list: the two x sides differ
+// List head = the low 11 bits of that word index | (cx & 1) << 11.  The 8 cells of a query never share a list: the two x sides differ
 // in cx & 1, and within one the word offsets {0, 1, B, B + 1} are distinct.
 constexpr unsigned kCellHashA = 97u;
 constexpr unsigned kCellHashB = 75u;
@@ -249,14 +250,14 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     const float inv_cs4 = 4.0f * inv_cs;
     auto cellq = [&](float v) -> unsigned { return __float_as_uint(__builtin_fmaf(v, inv_cs4, 12582912.0f)); };
     // ---------------- 2: mark the cells my query's padded box touches ----------------
-    // key of the low-corner cell (bits 0..12); bits 16..18: the box reaches into the next cell along x / y / z;
+    // key of the low-corner cell (bits 0..13); bits 16..18: the box reaches into the next cell along x / y / z;
     // bits 20..24: cx of the low corner mod 32
     unsigned qhash = 0u;
     auto corner_key = [&](int c) -> unsigned {
         return qhash + 4u * ((c & 1) * kCellHashA + ((c >> 1) & 1) + ((c >> 2) & 1) * kCellHashB);
     };
     auto corner_cx = [&](int c) -> unsigned { return (qhash >> 20) + (c & 1); };   // low 5 bits
-    auto head_of = [&](unsigned key, unsigned cx) -> unsigned { return ((key & kCellWordMask) >> 2) | ((cx & 1u) << 11); };
+    auto head_of = [&](unsigned key, unsigned cx) -> unsigned { return ((key >> 2) & 2047u) | ((cx & 1u) << 11); };
     {
         // pad: > radius plus the fp32 rounding of q -/+ rp
         const float qmax = fmaxf(fabsf(qx), fmaxf(fabsf(qy), fabsf(qz)));
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int
     const bool exh = sh.exh != 0;   // uniform
     load_points(std::integral_constant<int, kEarly>{}, std::integral_constant<int, kCellPPT>{}, 0);
 
-    // key of the cell of a point: the raw float bits go into the multiply-adds (24-bit operands; only bits 0..12 of the
-    // result are used and those depend on the low 13 bits of the operands alone); cx = raw bits of the x cell
+    // key of the cell of a point: the raw float bits go into the multiply-adds (24-bit operands; only bits 0..13 of the
+    // result are used and those depend on the low 14 bits of the operands alone); cx = raw bits of the x cell
     auto point_key = [&](float x, float y, float z, unsigned &cx) -> unsigned {
         cx = cellc(x);
         return mad_u24(cellc(z), 4u * kCellHashB, mad_u24(cx, 4u * kCellHashA, cellq(y)));
