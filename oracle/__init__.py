@@ -386,3 +386,26 @@ def bin_head_decode(head, ref_pts, ref_theta, mean_sizes_k, nbx, nbz, nbt, ss, d
                               _p(_f(np.asarray(deltas, np.float64).astype(np.float32))), ctypes.c_float(np.float32(r)),
                               ctypes.c_float(np.float32(delta_theta)), _p(c) if c is not None else None, _p(boxes))
     return boxes
+
+
+# ---- the per-point products of PointCNN's X-Conv (numpy, fp32 accumulation in index order) ----
+def xconv_apply(x, f):
+    """hf/core/feature_extractors/pointcnn.py:133  fts_X = tf.matmul(X, nn_fts_input): x (rows,K,K), f (rows,K,C) ->
+    (rows,K,C), out[r,i,:] = sum_j x[r,i,j] * f[r,j,:], the j in ascending order (the kernel's order)"""
+    x, f = _f(x), _f(f)
+    out = np.zeros_like(f)
+    for j in range(x.shape[2]):
+        out = out + x[:, :, j:j + 1] * f[:, j:j + 1, :] if j else x[:, :, 0:1] * f[:, 0:1, :]
+    return out
+
+
+def depthwise_k(x, w):
+    """hf/core/pointfly.py:437-457 depthwise_conv2d(.., (1,K)) on a width-K input (TensorFlow filter layout (1,K,C,M)):
+    x (rows,K,C), w (K,C,M) -> (rows, C*M), y[r, c*M + m] = sum_k x[r,k,c] * w[k,c,m], k ascending"""
+    x, w = _f(x), _f(w)
+    rows, k, c = x.shape
+    m = w.shape[2]
+    y = np.zeros((rows, c, m), np.float32)
+    for kk in range(k):
+        y = y + x[:, kk, :, None] * w[kk][None]
+    return y.reshape(rows, c * m)

@@ -164,3 +164,33 @@ def test_depthwise_k_kernel_against_conv2d(rows, k, c, m):
     assert torch.allclose(y.double(), ref, rtol=1e-5, atol=1e-5)
     assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-5, atol=1e-5)
     assert torch.allclose(w.grad.double(), wr.grad, rtol=1e-4, atol=1e-4 * max(1.0, rows ** 0.5))
+
+
+def test_oracle_xconv_products_against_conv2d():
+    """the oracle's restatement of the two X-Conv products, pinned on CPU against torch.matmul / a grouped conv2d with
+    TensorFlow's depthwise filter layout (the reference itself needs TensorFlow: parity unpinned beyond this)"""
+    import oracle
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((40, 8, 8)).astype(np.float32)
+    f = rng.standard_normal((40, 8, 37)).astype(np.float32)
+    np.testing.assert_allclose(oracle.xconv_apply(x, f), torch.matmul(torch.from_numpy(x), torch.from_numpy(f)).numpy(), rtol=1e-5, atol=1e-5)
+    xd = rng.standard_normal((30, 8, 13)).astype(np.float32)
+    w = rng.standard_normal((8, 13, 4)).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(xd).permute(0, 2, 1).unsqueeze(2), torch.from_numpy(w).permute(1, 2, 0).reshape(13 * 4, 1, 1, 8), groups=13)
+    np.testing.assert_allclose(oracle.depthwise_k(xd, w), ref.reshape(30, 52).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_xconv_kernels_against_oracle():
+    """hf_xconv_apply / hf_depthwise_k against the oracle: same multiply-then-add order, so bit for bit"""
+    import oracle
+    from heterofusionrcnn_amd import pointcnn
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((500, 8, 8)).astype(np.float32)
+    f = rng.standard_normal((500, 8, 320)).astype(np.float32)
+    got = pointcnn.x_apply(torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()).cpu().numpy()
+    assert np.array_equal(got, oracle.xconv_apply(x, f))
+    xd = rng.standard_normal((700, 8, 65)).astype(np.float32)
+    w = rng.standard_normal((8, 65, 4)).astype(np.float32)
+    got = pointcnn.depthwise_k(torch.from_numpy(xd).cuda(), torch.from_numpy(w).cuda()).cpu().numpy()
+    assert np.array_equal(got, oracle.depthwise_k(xd, w))
