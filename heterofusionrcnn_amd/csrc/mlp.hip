@@ -76,10 +76,17 @@ __device__ __forceinline__ void reduce_rows(float (&a)[VEC], float (&b)[VEC], in
     }
 }
 
+// `relu` argument of the BatchNorm entry points: bit 0 = ReLU after the normalisation (tf_util.conv2d), bit 1 = ELU BEFORE it
+// (pointfly.dense / conv2d: linear -> ELU -> batch_normalization, hf/core/pointfly.py:371-497): the statistics, the
+// normalisation and the backward pass then see elu(x), computed on load -- the activation never exists in memory.
+constexpr int kBnRelu = 1, kBnEluIn = 2;
+__device__ __forceinline__ float elu_fwd(float x) { return x > 0.0f ? x : expm1f(x); }
+__device__ __forceinline__ float elu_slope(float x) { return x > 0.0f ? 1.0f : expf(x); }
+
 // partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over the block's rows
 template <int VEC>
 __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
-                                const float *__restrict__ x, float *__restrict__ partial)
+                                const float *__restrict__ x, float *__restrict__ partial, int elu_in)
 {
     extern __shared__ float smem[];
     const int t = threadIdx.x;
@@ -92,7 +99,7 @@ __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long lon
     for (long long r = r0 + rsub; r < r1; r += rpb) {
         const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { const float f = vget<VEC>(v, i); s[i] += f; q[i] += f * f; }
+        for (int i = 0; i < VEC; ++i) { float f = vget<VEC>(v, i); if (elu_in) f = elu_fwd(f); s[i] += f; q[i] += f * f; }
     }
     reduce_rows<VEC>(s, q, cv, rpb, cvec, rsub, smem);
     if (rsub == 0) {
@@ -172,8 +179,10 @@ __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long lon
         typename VecT<VEC>::type o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            float h = a[i] * vget<VEC>(v, i) + b[i];
-            if (relu) h = fmaxf(h, 0.0f);
+            float xv = vget<VEC>(v, i);
+            if (relu & kBnEluIn) xv = elu_fwd(xv);
+            float h = a[i] * xv + b[i];
+            if (relu & kBnRelu) h = fmaxf(h, 0.0f);
             vset<VEC>(o, i, h);
         }
         stv<VEC>(y + r * c + cvec * VEC, o);
@@ -207,9 +216,10 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
         const typename VecT<VEC>::type g = ldv<VEC>(dy + r * c + cvec * VEC);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const float xv = vget<VEC>(v, i);
+            float xv = vget<VEC>(v, i);
+            if (relu & kBnEluIn) xv = elu_fwd(xv);
             float dh = vget<VEC>(g, i);
-            if (relu && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
+            if ((relu & kBnRelu) && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
             s1[i] += dh;
             s2[i] += dh * ((xv - mu[i]) * is[i]);
         }
@@ -267,11 +277,13 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
         typename VecT<VEC>::type o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const float xv = vget<VEC>(v, i);
+            const float xraw = vget<VEC>(v, i);
+            const float xv = (relu & kBnEluIn) ? elu_fwd(xraw) : xraw;
             float dh = vget<VEC>(g, i);
-            if (relu && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
+            if ((relu & kBnRelu) && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
             const float xhat = (xv - mu[i]) * is[i];
-            const float d = a[i] * (dh - c1[i] - xhat * c2[i]);
+            float d = a[i] * (dh - c1[i] - xhat * c2[i]);
+            if (relu & kBnEluIn) d = d * elu_slope(xraw);
             cs[i] += d;
             vset<VEC>(o, i, d);
         }
@@ -479,10 +491,10 @@ HF_API int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const flo
     const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial);
+                           g.rows_per_block, x, partial, (relu & kBnEluIn) ? 1 : 0);
     else
         hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial);
+                           g.rows_per_block, x, partial, (relu & kBnEluIn) ? 1 : 0);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd);
     if (g.vec == 4)
@@ -507,10 +519,10 @@ HF_API int hf_bn_stats(long long rows, int c, const float *x, float eps, float m
     const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial);
+                           g.rows_per_block, x, partial, 0);
     else
         hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial);
+                           g.rows_per_block, x, partial, 0);
     launch_bn_stats_finalize(rows, c, g.nblk, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd, st);
     return launch_status();
 }
@@ -603,10 +615,10 @@ HF_API int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z
         const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
         if (g.vec == 4)
             hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                               g.rows_per_block, z, partial);
+                               g.rows_per_block, z, partial, 0);
         else
             hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                               g.rows_per_block, z, partial);
+                               g.rows_per_block, z, partial, 0);
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps, momentum,
                            running_mean, running_var, mean, invstd);
     }

@@ -31,10 +31,10 @@ class _BNReLUTrain(torch.autograd.Function):
         invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
         ws, nbytes = _workspace(rows, c, x.device)
         check(_lib.lib().hf_bn_relu_fwd_train(rows, c, ptr(x), ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
-                                              ptr(running_var), 1 if relu else 0, ptr(y), ptr(mean), ptr(invstd),
+                                              ptr(running_var), int(relu), ptr(y), ptr(mean), ptr(invstd),
                                               ptr(ws), nbytes, stream_ptr()), "bn_relu_fwd_train")
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
-        ctx.relu = relu
+        ctx.relu = int(relu)   # mode bits: 1 = ReLU after, 2 = ELU before
         return y
 
     @staticmethod
@@ -47,7 +47,7 @@ class _BNReLUTrain(torch.autograd.Function):
         dbeta = torch.empty_like(beta)
         ws, nbytes = _workspace(rows, c, x.device)
         check(_lib.lib().hf_bn_relu_bwd(rows, c, ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
-                                        1 if ctx.relu else 0, ptr(dx), ptr(dgamma), ptr(dbeta), None, ptr(ws), nbytes,
+                                        ctx.relu, ptr(dx), ptr(dgamma), ptr(dbeta), None, ptr(ws), nbytes,
                                         stream_ptr()), "bn_relu_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None
 
@@ -452,9 +452,11 @@ class BatchNormReLU(nn.Module):
     """BatchNorm over the last dimension of (rows, C) followed by ReLU, one fused op.
     Parameter / buffer names follow nn.BatchNorm1d (weight, bias, running_mean, running_var)."""
 
-    def __init__(self, num_features, eps=1e-3, momentum=0.1, relu=True):
+    def __init__(self, num_features, eps=1e-3, momentum=0.1, relu=True, elu_in=False):
+        """elu_in: ELU applied to the input on load (pointfly's linear -> ELU -> BatchNorm), fused into every pass"""
         super().__init__()
         self.num_features, self.eps, self.momentum, self.relu = num_features, eps, momentum, relu
+        self.elu_in = elu_in
         self.weight = nn.Parameter(torch.ones(num_features))   # gamma: tf.constant_initializer(1.0)
         self.bias = nn.Parameter(torch.zeros(num_features))    # beta: 0
         self.register_buffer("running_mean", torch.zeros(num_features))
@@ -467,11 +469,12 @@ class BatchNormReLU(nn.Module):
         x = x.contiguous()
         if self.training:
             return _BNReLUTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
-                                      self.momentum, self.relu)
+                                      self.momentum, (1 if self.relu else 0) | (2 if self.elu_in else 0))
         y = torch.empty_like(x)
         invstd = torch.rsqrt(self.running_var + self.eps)
         check(_lib.lib().hf_bn_relu_fwd_eval(x.shape[0], x.shape[1], ptr(x), ptr(self.weight), ptr(self.bias),
-                                             ptr(self.running_mean), ptr(invstd), 1 if self.relu else 0, ptr(y),
+                                             ptr(self.running_mean), ptr(invstd),
+                                             (1 if self.relu else 0) | (2 if self.elu_in else 0), ptr(y),
                                              stream_ptr()), "bn_relu_fwd_eval")
         return y
 

@@ -36,19 +36,18 @@ from .mlp import BatchNormReLU, linear_nobias
 
 
 class EluBN(nn.Module):
-    """activation (ELU or none) then tf.layers.batch_normalization(momentum 0.99, epsilon 1e-3) over the last dimension"""
+    """activation (ELU or none) then tf.layers.batch_normalization(momentum 0.99, epsilon 1e-3) over the last dimension.
+    The ELU is applied on load inside the HIP BatchNorm passes (statistics, normalisation, both backward passes): the
+    activated tensor never exists in memory."""
 
     def __init__(self, channels, activation=True):
         super().__init__()
-        self.bn = BatchNormReLU(channels, eps=1e-3, momentum=0.01, relu=False)
+        self.bn = BatchNormReLU(channels, eps=1e-3, momentum=0.01, relu=False, elu_in=activation)
         self.activation = activation
 
     def forward(self, x):
         shape = x.shape
-        x = x.reshape(-1, shape[-1])
-        if self.activation:
-            x = F.elu(x)
-        return self.bn(x).reshape(shape)
+        return self.bn(x.reshape(-1, shape[-1])).reshape(shape)
 
 
 class Dense(nn.Module):

@@ -244,14 +244,12 @@ class DenseEluBN(nn.Module):
         super().__init__()
         self.linear = nn.Linear(cin, cout, bias=False)
         nn.init.xavier_normal_(self.linear.weight)                 # glorot_normal_initializer
-        self.bn = BatchNormReLU(cout, eps=1e-3, momentum=0.01, relu=False)   # the HIP statistics / apply / backward passes
+        # the HIP statistics / apply / backward passes, with the ELU applied on load inside them
+        self.bn = BatchNormReLU(cout, eps=1e-3, momentum=0.01, relu=False, elu_in=activation)
         self.activation = activation
 
     def forward(self, x):
-        y = linear_nobias(x, self.linear.weight)
-        if self.activation:
-            y = F.elu(y)
-        return self.bn(y)
+        return self.bn(linear_nobias(x, self.linear.weight))
 
 
 class RpnHeads(nn.Module):

@@ -184,7 +184,10 @@ int hf_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz
  * (hf/core/feature_extractors/tf_util.py:190-203,554-581; decay = 1 - momentum, epsilon = eps).
  * Batch statistics are reduced deterministically (per-block fp32 partials, fp64 final reduction).
  * running_mean / running_var (may be NULL) are updated as (1-momentum)*running + momentum*batch
- * (unbiased variance).  save_mean / save_invstd (c floats each) feed the backward pass.
+ * (biased variance, as TensorFlow's moments).  save_mean / save_invstd (c floats each) feed the backward pass.
+ * `relu` (all BatchNorm entry points that take it): bit 0 = ReLU after the normalisation; bit 1 = ELU applied to x on
+ * load, before the statistics and the normalisation (pointfly.dense / conv2d: linear -> ELU -> batch_normalization,
+ * hf/core/pointfly.py:371-497): 0 none, 1 BN+ReLU, 2 ELU+BN.
  * workspace: hf_bn_workspace(rows, c) bytes of device scratch. */
 size_t hf_bn_workspace(long long rows, int c);
 int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps,

@@ -1607,3 +1607,32 @@ def test_fused_linear_bn_relu_maxpool_node(hf, groups, k, cin, cout):
         e1 = torch.relu(ref_bn(ref_fc(x1))).view(groups, k, cout).max(dim=1).values
         e2 = linear_bn_relu_maxpool(x2.detach(), layer.fc.weight, layer.fc.bias, layer.bn, k)
     torch.testing.assert_close(e2, e1, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 64), (4099, 76), (300, 7)])
+def test_bn_with_elu_on_load(hf, rows, c):
+    """BatchNormReLU(elu_in=True) = batch_norm(elu(x)) of pointfly.dense (pointfly.py:371-497), forward, running statistics
+    and all gradients, against torch in fp64"""
+    from heterofusionrcnn_amd.mlp import BatchNormReLU
+    g = torch.Generator().manual_seed(rows + c)
+    x = torch.randn(rows, c, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(rows, c, generator=g).cuda()
+    bn = BatchNormReLU(c, eps=1e-3, momentum=0.01, relu=False, elu_in=True).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5); bn.bias.copy_(torch.randn(c, generator=g))
+    y = bn(x); y.backward(dy)
+    xr = x.detach().double().requires_grad_(True)
+    w, b = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    e = torch.nn.functional.elu(xr)
+    mean, var = e.mean(0), e.var(0, unbiased=False)
+    ref = (e - mean) / torch.sqrt(var + 1e-3) * w + b
+    ref.backward(dy.double())
+    assert torch.allclose(y.double(), ref, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(bn.weight.grad.double(), w.grad, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(bn.bias.grad.double(), b.grad, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(bn.running_mean.double(), 0.01 * mean.detach(), rtol=1e-3, atol=1e-5)
+    bn.eval()
+    ye = bn(x.detach())
+    refe = (e.detach() - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + 1e-3) * w.detach() + b.detach()
+    assert torch.allclose(ye.double(), refe, rtol=1e-4, atol=1e-4)
