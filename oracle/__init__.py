@@ -409,3 +409,17 @@ def depthwise_k(x, w):
     for kk in range(k):
         y = y + x[:, kk, :, None] * w[kk][None]
     return y.reshape(rows, c * m)
+
+
+def knn_point_three_term(k, xyz1, xyz2):
+    """grouping/tf_grouping.py:80-92 as written: dist = |q|^2 - 2 q.p^T + |p|^2 in fp32 (may go slightly negative),
+    then tf.nn.top_k(-dist, k) (equal values: the lower index first).  Used by the tests to assert that the (q - p)^2
+    kernel returns the same neighbour sets wherever the k-th gap exceeds the rounding of this expansion; the matmul's
+    fp32 summation order inside TensorFlow is not reproducible here, so near-ties stay parity unpinned."""
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    r1 = np.sum(xyz1 * xyz1, axis=2, keepdims=True, dtype=np.float32)                  # (b, n, 1)
+    r2 = np.sum(xyz2 * xyz2, axis=2, keepdims=True, dtype=np.float32)                  # (b, m, 1)
+    mul = np.matmul(xyz2, np.transpose(xyz1, (0, 2, 1))).astype(np.float32)             # (b, m, n)
+    dist = (r2 - np.float32(2) * mul + np.transpose(r1, (0, 2, 1))).astype(np.float32)
+    idx = np.argsort(dist, axis=2, kind="stable")[:, :, :k].astype(np.int32)            # stable: lower index first on ties
+    return np.take_along_axis(dist, idx, axis=2), idx

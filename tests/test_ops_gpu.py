@@ -1636,3 +1636,26 @@ def test_bn_with_elu_on_load(hf, rows, c):
     ye = bn(x.detach())
     refe = (e.detach() - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + 1e-3) * w.detach() + b.detach()
     assert torch.allclose(ye.double(), refe, rtol=1e-4, atol=1e-4)
+
+
+def test_knn_point_against_three_term_formula(hf, oracle_mod):
+    """knn_point (exact (q-p)^2, ties to the lower index) against the reference's expression restated as written
+    (tf_grouping.py:80-92: |q|^2 - 2 q.p^T + |p|^2, top_k): the neighbour SETS must agree wherever the gap between the
+    k-th and the (k+1)-th distance exceeds the rounding of the expansion; near-ties are parity unpinned and only counted"""
+    rng = np.random.default_rng(21)
+    k = 8
+    x1 = kitti_uniform(rng, 2, 4096)
+    x2 = x1[:, rng.permutation(4096)[:1024]]
+    val, idx = hf.knn_point(k, dev(x1), dev(x2))
+    idx = host(idx)
+    tv, ti = oracle_mod.knn_point_three_term(k, x1, x2)
+    d = ((x2[:, :, None, :].astype(np.float64) - x1[:, None, :, :].astype(np.float64)) ** 2).sum(-1)
+    ds = np.sort(d, axis=2)
+    # rounding of the expansion: a few ulp of |q|^2 + |p|^2 (coordinates up to 70 m -> magnitudes ~ 1e4, ulp ~ 1e-3)
+    scale = (x2.astype(np.float64) ** 2).sum(-1)[:, :, None] * 2 + 1.0
+    clear = (ds[:, :, k] - ds[:, :, k - 1]) > 4e-6 * scale[:, :, 0]
+    same = np.array([[set(idx[b, j]) == set(ti[b, j]) for j in range(idx.shape[1])] for b in range(idx.shape[0])])
+    assert clear.mean() > 0.5, "the test must check most queries"
+    assert same[clear].all(), "neighbour sets differ where the k-th gap exceeds the rounding of the three-term formula"
+    # the kernel's own distances are the exact ones
+    np.testing.assert_allclose(host(val), np.take_along_axis(d, idx.astype(np.int64), axis=2), rtol=1e-5, atol=1e-5)
