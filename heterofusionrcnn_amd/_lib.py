@@ -79,6 +79,8 @@ _SIGNATURES = {
     "hf_xconv_apply_grad": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_depthwise_k": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_depthwise_k_grad": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hf_xconv_depthwise": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "hf_xconv_depthwise_grad": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_version": [],
     "hf_strerror": [_i],
     "hf_last_hip_error": [],

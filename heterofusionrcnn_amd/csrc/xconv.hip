@@ -204,6 +204,158 @@ __global__ __launch_bounds__(kXcThreads) void depthwise_dw_kernel(long long rows
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// X-transform apply and the depthwise step of the separable convolution in one pass (pointcnn.py:133-140):
+//   out[r][ch*M + m] = sum_k (sum_j X[r][k][j] * F[r][j][ch]) * Wd[k][ch][m]
+// F_X = X x F_* (rows x K x C, the largest tensor of an X-Conv: 1.3 GB for the decoder layers at 131 072 points) is never
+// written: the K products of a (row, channel) stay in registers.  Same multiply / add order as hf_xconv_apply followed by
+// hf_depthwise_k, so the results are bit-identical to the two-kernel route.
+// Mapping: a lane owns ONE channel for the whole kernel (its K x M depthwise weights live in registers, blockIdx.y picks
+// the 64-channel chunk), the four waves of a block walk the rows of a chunk; the row's K x K matrix is wave-uniform.
+template <int K, int M>
+__global__ __launch_bounds__(kXcThreads) void xconv_dw_fwd_kernel(long long rows, int c, int rows_per_block,
+                                                                 const float *__restrict__ x, const float *__restrict__ f,
+                                                                 const float *__restrict__ wd, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int ch = blockIdx.y * 64 + lane;
+    const bool live = ch < c;
+    float w[K][M];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int m = 0; m < M; ++m) w[k][m] = live ? wd[(static_cast<size_t>(k) * c + ch) * M + m] : 0.f;
+    const long long r0 = static_cast<long long>(blockIdx.x) * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long long r = r0 + wave; r < r1; r += kXcThreads / 64) {
+        const float *xr = x + r * (K * K);
+        float fv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) fv[j] = live ? f[(r * K + j) * c + ch] : 0.f;
+        float o[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) o[m] = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float t = xr[k * K] * fv[0];
+#pragma unroll
+            for (int j = 1; j < K; ++j) t = t + xr[k * K + j] * fv[j];
+#pragma unroll
+            for (int m = 0; m < M; ++m) o[m] = o[m] + t * w[k][m];
+        }
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) out[(r * c + ch) * M + m] = o[m];
+        }
+    }
+}
+
+// gradients w.r.t. F and Wd, same mapping: per (row, channel) the gradient of F_X (K values), F_X itself (recomputed) and
+// the K input gradients stay in registers; a lane sums its channel's K x M weight gradients over its rows and adds them
+// to grad_wd with one atomic per coefficient (grad_wd zero-filled by the entry point)
+template <int K, int M>
+__global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long rows, int c, int rows_per_block,
+                                                                    const float *__restrict__ x, const float *__restrict__ f,
+                                                                    const float *__restrict__ wd, const float *__restrict__ grad_out,
+                                                                    float *__restrict__ grad_f, float *__restrict__ grad_wd)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int ch = blockIdx.y * 64 + lane;
+    const bool live = ch < c;
+    float w[K][M], gw[K][M];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int m = 0; m < M; ++m) { w[k][m] = live ? wd[(static_cast<size_t>(k) * c + ch) * M + m] : 0.f; gw[k][m] = 0.f; }
+    const long long r0 = static_cast<long long>(blockIdx.x) * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long long r = r0 + wave; r < r1; r += kXcThreads / 64) {
+        const float *xr = x + r * (K * K);
+        float fv[K], g[M], gfx[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) fv[j] = live ? f[(r * K + j) * c + ch] : 0.f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) g[m] = live ? grad_out[(r * c + ch) * M + m] : 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < M; ++m) a = a + g[m] * w[k][m];          // = hf_depthwise_k_grad's dx
+            gfx[k] = a;
+            float t = xr[k * K] * fv[0];                                  // F_X recomputed
+#pragma unroll
+            for (int j = 1; j < K; ++j) t = t + xr[k * K + j] * fv[j];
+#pragma unroll
+            for (int m = 0; m < M; ++m) gw[k][m] = gw[k][m] + t * g[m];   // = hf_depthwise_k_grad's dw
+        }
+        if (live && grad_f) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                float a = xr[j] * gfx[0];                                  // = hf_xconv_apply_grad's dF (X transposed)
+#pragma unroll
+                for (int k = 1; k < K; ++k) a = a + xr[k * K + j] * gfx[k];
+                grad_f[(r * K + j) * c + ch] = a;
+            }
+        }
+    }
+    if (live && grad_wd) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int m = 0; m < M; ++m) atomicAdd(&grad_wd[(static_cast<size_t>(k) * c + ch) * M + m], gw[k][m]);
+    }
+}
+
+// gradient w.r.t. X: dX[r][k][j] = sum_ch dF_X[r][k][ch] * F[r][j][ch] with dF_X rebuilt from grad_out and Wd on the fly;
+// a wave per row, the 64 partial K x K matrices of the lanes meet in LDS (as xconv_dx_kernel)
+template <int K, int M>
+__global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_x_kernel(long long rows, int c, const float *__restrict__ f,
+                                                                   const float *__restrict__ wd, const float *__restrict__ grad_out,
+                                                                   float *__restrict__ grad_x)
+{
+    extern __shared__ float lds[];
+    constexpr int KK = K * K, STRIDE = KK + 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float *mine = lds + static_cast<size_t>(w) * 64 * STRIDE;
+    const long long wave = w + static_cast<long long>(blockIdx.x) * (kXcThreads / 64);
+    const long long nwaves = static_cast<long long>(gridDim.x) * (kXcThreads / 64);
+    for (long long r = wave; r < rows; r += nwaves) {
+        float acc[K][K];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[i][j] = 0.f;
+        for (int ch = lane; ch < c; ch += 64) {
+            float fv[K], g[M];
+#pragma unroll
+            for (int j = 0; j < K; ++j) fv[j] = f[(r * K + j) * c + ch];
+#pragma unroll
+            for (int m = 0; m < M; ++m) g[m] = grad_out[(r * c + ch) * M + m];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; ++m) a = a + g[m] * wd[(static_cast<size_t>(k) * c + ch) * M + m];
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[k][j] = acc[k][j] + a * fv[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) mine[lane * STRIDE + i * K + j] = acc[i][j];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int p = lane; p < KK; p += 64) {
+            float s = 0.f;
+            for (int l = 0; l < 64; ++l) s = s + mine[l * STRIDE + p];
+            grad_x[r * KK + p] = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 static int grid_for(long long items, int per_block)
 {
     const long long blocks = (items + per_block - 1) / per_block;
@@ -319,6 +471,74 @@ HF_API int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float 
 #define HF_DW_DW(KK, MM) hipLaunchKernelGGL((depthwise_dw_kernel<KK, MM>), grid, dim3(kXcThreads), lds, st, rows, c, rows_per_chunk, x, grad_y, grad_w);
         HF_DW_DISPATCH(HF_DW_DW)
 #undef HF_DW_DW
+        return launch_status();
+    }
+    return HF_OK;
+}
+
+// (k, m) supported by the fused X-apply + depthwise kernels: k = 8, m = 1..4 (the separable convolutions of pointcnn.py:259-265)
+#define HF_XDW_DISPATCH(CALL)                                                                                          \
+    if (k == 8 && m == 1) { CALL(8, 1) } else if (k == 8 && m == 2) { CALL(8, 2) } else if (k == 8 && m == 3) { CALL(8, 3) }      \
+    else if (k == 8 && m == 4) { CALL(8, 4) } else return HF_EINVAL;
+
+static void xdw_grid(long long rows, int c, dim3 &grid, int &rows_per_block)
+{
+    const int cchunks = div_up(c, 64);
+    long long rchunks = (8 * kNumCU + cchunks - 1) / cchunks;   // ~8 blocks per CU in total
+    if (rchunks > (rows + 3) / 4) rchunks = (rows + 3) / 4;
+    if (rchunks < 1) rchunks = 1;
+    rows_per_block = static_cast<int>((rows + rchunks - 1) / rchunks);
+    grid = dim3(static_cast<unsigned>((rows + rows_per_block - 1) / rows_per_block), cchunks);
+}
+
+HF_API int hf_xconv_depthwise(long long rows, int k, int c, int m, const float *x, const float *f, const float *wd, float *out,
+                              hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !f || !wd || !out) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    dim3 grid;
+    int rpb;
+    xdw_grid(rows, c, grid, rpb);
+#define HF_XDW_FWD(KK, MM) hipLaunchKernelGGL((xconv_dw_fwd_kernel<KK, MM>), grid, dim3(kXcThreads), 0, as_stream(stream), rows, c, rpb, x, f, wd, out);
+    HF_XDW_DISPATCH(HF_XDW_FWD)
+#undef HF_XDW_FWD
+    return launch_status();
+}
+
+HF_API int hf_xconv_depthwise_grad(long long rows, int k, int c, int m, const float *x, const float *f, const float *wd,
+                                   const float *grad_out, float *grad_x, float *grad_f, float *grad_wd, hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !f || !wd || !grad_out || (!grad_x && !grad_f && !grad_wd)) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (grad_wd) {
+        const int rc = hip_status(hipMemsetAsync(grad_wd, 0, sizeof(float) * static_cast<size_t>(k) * c * m, st));
+        if (rc != HF_OK) return rc;
+    }
+    if (rows == 0) return HF_OK;
+    if (grad_f || grad_wd) {
+        dim3 grid;
+        int rpb;
+        xdw_grid(rows, c, grid, rpb);
+#define HF_XDW_BFW(KK, MM) hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM>), grid, dim3(kXcThreads), 0, st, rows, c, rpb, x, f, wd, grad_out, grad_f, grad_wd);
+        HF_XDW_DISPATCH(HF_XDW_BFW)
+#undef HF_XDW_BFW
+        const int rc = launch_status();
+        if (rc != HF_OK) return rc;
+    }
+    if (grad_x) {
+        const size_t lds = sizeof(float) * (kXcThreads / 64) * 64 * (8 * 8 + 1);
+        static bool raised = false;
+#define HF_XDW_BX(KK, MM)                                                                                              \
+        if (!raised) {                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+            raised = true;                                                                                             \
+        }                                                                                                              \
+        hipLaunchKernelGGL((xconv_dw_bwd_x_kernel<KK, MM>), dim3(grid_for(rows, kXcThreads / 64)), dim3(kXcThreads), lds, st, rows, c, f, wd, grad_out, grad_x);
+        HF_XDW_DISPATCH(HF_XDW_BX)
+#undef HF_XDW_BX
         return launch_status();
     }
     return HF_OK;

@@ -135,6 +135,48 @@ class _XApply(torch.autograd.Function):
         return (gx.reshape(sx) if gx is not None else None), (gf.reshape(sf) if gf is not None else None)
 
 
+class _XConvDepthwise(torch.autograd.Function):
+    """hf_xconv_depthwise (+ grad): F_X = X x F_* and the depthwise half of the separable convolution in one pass; the
+    (B,P,K,C) product is neither stored in the forward pass nor read back in the backward pass (recomputed in registers)"""
+
+    @staticmethod
+    def forward(ctx, x, f, wd):
+        k, c, m = wd.shape
+        x2 = x.reshape(-1, k, k).contiguous()
+        f2 = f.reshape(-1, k, c).contiguous()
+        w = wd.contiguous()
+        out = torch.empty((f2.shape[0], c * m), dtype=torch.float32, device=f.device)
+        check(_lib.lib().hf_xconv_depthwise(f2.shape[0], k, c, m, ptr(x2), ptr(f2), ptr(w), ptr(out), stream_ptr()),
+              "xconv_depthwise")
+        ctx.save_for_backward(x2, f2, w)
+        ctx.shapes = (tuple(x.shape), tuple(f.shape))
+        return out.reshape(*f.shape[:-2], c * m)
+
+    @staticmethod
+    def backward(ctx, go):
+        x2, f2, w = ctx.saved_tensors
+        k, c, m = w.shape
+        go = go.reshape(-1, c * m).contiguous()
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gf = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[2] else None
+        check(_lib.lib().hf_xconv_depthwise_grad(f2.shape[0], k, c, m, ptr(x2), ptr(f2), ptr(w), ptr(go), ptr(gx), ptr(gf),
+                                                 ptr(gw), stream_ptr()), "xconv_depthwise_grad")
+        sx, sf = ctx.shapes
+        return (gx.reshape(sx) if gx is not None else None), (gf.reshape(sf) if gf is not None else None), gw
+
+
+_XDW_KM = {(8, 1), (8, 2), (8, 3), (8, 4)}
+
+
+def xconv_depthwise(x, f, wd):
+    """depthwise_k(x @ f, wd): x (.., K, K), f (.., K, C), wd (K, C, M) -> (.., C*M)"""
+    k, c, m = wd.shape
+    if _hip_ok(x, f, wd) and (k, m) in _XDW_KM and f.shape[-2] == k and f.shape[-1] == c and x.shape[-1] == x.shape[-2] == k:
+        return _XConvDepthwise.apply(x, f, wd)
+    return depthwise_k(x_apply(x, f), wd)
+
+
 def x_apply(x, f):
     """x (.., K, K), f (.., K, C) -> (.., K, C) = x @ f"""
     if _hip_ok(x, f) and f.shape[-2] in _XAPPLY_K and x.shape[-1] == x.shape[-2] == f.shape[-2]:
@@ -209,8 +251,10 @@ class XConv(nn.Module):
             x = self.x0(local.reshape(b, p, 1, k * 3)).reshape(b, p, k, k)
             x = self.x1(x).reshape(b, p, k, k)
             x = self.x2(x).reshape(b, p, k, k)
-            f = x_apply(x, f)                                 # F_X <- X x F_*
-        out = self.conv(f)                                    # (B,P,C)
+            # F_X <- X x F_*, then the depthwise half of the separable convolution, in one pass
+            out = self.conv.post(linear_nobias(xconv_depthwise(x, f, self.conv.depthwise), self.conv.pointwise.weight))
+        else:
+            out = self.conv(f)                                # (B,P,C)
         if self.with_global:
             out = torch.cat([self.g1(self.g0(qrs)), out], dim=-1)
         return out

@@ -194,3 +194,25 @@ def test_xconv_kernels_against_oracle():
     w = rng.standard_normal((8, 65, 4)).astype(np.float32)
     got = pointcnn.depthwise_k(torch.from_numpy(xd).cuda(), torch.from_numpy(w).cuda()).cpu().numpy()
     assert np.array_equal(got, oracle.depthwise_k(xd, w))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,c,m", [(1, 1, 1), (37, 65, 4), (300, 320, 1), (129, 640, 2), (2048, 1280, 1), (50, 70, 3)])
+def test_fused_xconv_depthwise_equals_two_kernels(rows, c, m):
+    """hf_xconv_depthwise (+ grad) against hf_xconv_apply followed by hf_depthwise_k: forward bit for bit (same multiply /
+    add order), gradients to rounding (the weight gradient is accumulated with atomics in both routes)"""
+    from heterofusionrcnn_amd import pointcnn
+    g = torch.Generator().manual_seed(rows + c + m)
+    k = 8
+    mk = lambda *s: torch.randn(*s, generator=g).cuda().requires_grad_(True)
+    x, f, w = mk(rows, k, k), mk(rows, k, c), mk(k, c, m)
+    go = torch.randn(rows, c * m, generator=g).cuda()
+    out = pointcnn.xconv_depthwise(x, f, w)
+    out.backward(go)
+    x2, f2, w2 = (t.detach().clone().requires_grad_(True) for t in (x, f, w))
+    ref = pointcnn.depthwise_k(pointcnn.x_apply(x2, f2), w2)
+    ref.backward(go)
+    assert torch.equal(out, ref)
+    assert torch.allclose(f.grad, f2.grad, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-5, atol=1e-5 * max(1.0, c ** 0.5))
+    assert torch.allclose(w.grad, w2.grad, rtol=1e-4, atol=1e-4 * max(1.0, rows ** 0.5))
