@@ -75,6 +75,8 @@ _SIGNATURES = {
     "hf_bin_box_decode": [ctypes.c_longlong, _i] + [_vp] * 13 + [_f, _f, _vp, _vp],
     "hf_bin_box_encode": [ctypes.c_longlong, _i, _i] + [_vp] * 7 + [_f, _f, _f, _f] + [_vp] * 8 + [_vp],
     "hf_bin_head_decode": [ctypes.c_longlong, _i, _i, _i, _i] + [_vp] * 6 + [_f, _f, _vp, _vp, _vp],
+    "hf_group_point_into": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "hf_group_point_grad_from": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_xconv_apply": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp],
     "hf_xconv_apply_grad": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_depthwise_k": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp],

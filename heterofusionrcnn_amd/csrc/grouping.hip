@@ -349,6 +349,42 @@ __global__ void select_top_k_kernel(int n, long long nrows, int k, const float *
     }
 }
 
+// group_point writing into / its gradient reading from a COLUMN SLICE of wider rows: out[row][col .. col+c) of rows of
+// `width` floats.  PointCNN concatenates the lifted coordinates with the gathered features of the previous layer
+// (pointcnn.py:96-99): gathering straight into the concat buffer saves the copy of the larger part of it, and the gradient
+// of the concat is read in place.
+template <int VEC>
+__global__ void group_point_into_kernel(int n, int c, int width, int col, long long rows_per_batch, long long nrows,
+                                        const float *__restrict__ points, const int *__restrict__ idx, float *__restrict__ out)
+{
+    const int cv = c / VEC;
+    const long long total = nrows * cv;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / cv;
+        const int l = static_cast<int>(e - row * cv) * VEC;
+        const long long bb = row / rows_per_batch;
+        const float *src = points + (bb * n + idx[row]) * c + l;
+        float *dst = out + row * width + col + l;
+        if (VEC == 4) *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+        else dst[0] = src[0];
+    }
+}
+
+__global__ void group_point_grad_from_kernel(int n, int c, int width, int col, long long rows_per_batch, long long nrows,
+                                             const float *__restrict__ grad_out, const int *__restrict__ idx,
+                                             float *__restrict__ grad_points)
+{
+    const long long total = nrows * c;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / c;
+        const int l = static_cast<int>(e - row * c);
+        const long long bb = row / rows_per_batch;
+        atomicAdd(grad_points + (bb * n + idx[row]) * c + l, grad_out[row * width + col + l]);
+    }
+}
+
 static int grid_for(long long work_items, int block)
 {
     long long g = (work_items + block - 1) / block;
@@ -674,6 +710,43 @@ HF_API int hf_group_point_grad(int b, int n, int c, int m, int nsample, const fl
     if (nrows == 0) return HF_OK;
     const int block = 256;
     hipLaunchKernelGGL(group_point_grad_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c,
+                       static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);
+    return launch_status();
+}
+
+HF_API int hf_group_point_into(int b, int n, int c, int m, int nsample, int width, int col, const float *points, const int *idx,
+                               float *out, hf_stream_t stream)
+{
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || col < 0 || width < col + c || !points || !idx || !out) return HF_EINVAL;
+    const long long nrows = static_cast<long long>(b) * m * nsample;
+    if (nrows == 0) return HF_OK;
+    const long long rpb = static_cast<long long>(m) * nsample;
+    const int block = 256;
+    hipStream_t st = as_stream(stream);
+    const bool vec = c % 4 == 0 && width % 4 == 0 && col % 4 == 0 && reinterpret_cast<uintptr_t>(points) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(out) % 16 == 0;
+    if (vec)
+        hipLaunchKernelGGL((group_point_into_kernel<4>), dim3(grid_for(nrows * (c / 4), block)), dim3(block), 0, st, n, c, width, col,
+                           rpb, nrows, points, idx, out);
+    else
+        hipLaunchKernelGGL((group_point_into_kernel<1>), dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c, width, col, rpb,
+                           nrows, points, idx, out);
+    return launch_status();
+}
+
+HF_API int hf_group_point_grad_from(int b, int n, int c, int m, int nsample, int width, int col, const float *grad_out,
+                                    const int *idx, float *grad_points, hf_stream_t stream)
+{
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || col < 0 || width < col + c || !grad_out || !idx || !grad_points)
+        return HF_EINVAL;
+    if (b == 0) return HF_OK;
+    hipStream_t st = as_stream(stream);
+    int rc = hip_status(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(b) * n * c, st));
+    if (rc != HF_OK) return rc;
+    const long long nrows = static_cast<long long>(b) * m * nsample;
+    if (nrows == 0) return HF_OK;
+    const int block = 256;
+    hipLaunchKernelGGL(group_point_grad_from_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c, width, col,
                        static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);
     return launch_status();
 }

@@ -60,6 +60,46 @@ def group_point(points, idx):
     return _GroupPoint.apply(points, idx)
 
 
+class _ConcatGroup(torch.autograd.Function):
+    """[head | points[idx]]: the gathered part is written straight into the concat buffer and its gradient is read out
+    of the concat's gradient in place (hf_group_point_into / hf_group_point_grad_from); only `head` is copied"""
+
+    @staticmethod
+    def forward(ctx, head, points, idx):
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        ch = head.shape[-1]
+        out = torch.empty((b, m, ns, ch + c), dtype=torch.float32, device=points.device)
+        out[..., :ch].copy_(head)
+        check(_lib.lib().hf_group_point_into(b, n, c, m, ns, ch + c, ch, ptr(points), ptr(idx), ptr(out), stream_ptr()),
+              "group_point_into")
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, n, c, ch)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, n, c, ch = ctx.shape
+        _, m, ns = idx.shape
+        grad_out = grad_out.contiguous()
+        g = None
+        if ctx.needs_input_grad[1]:
+            g = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
+            check(_lib.lib().hf_group_point_grad_from(b, n, c, m, ns, ch + c, ch, ptr(grad_out), ptr(idx), ptr(g), stream_ptr()),
+                  "group_point_grad_from")
+        return (grad_out[..., :ch] if ctx.needs_input_grad[0] else None), g, None
+
+
+def concat_group(head, points, idx):
+    """torch.cat([head, group_point(points, idx)], -1) for head (B,M,K,Ch), points (B,N,C), idx (B,M,K)"""
+    require(head.dim() == 4 and points.dim() == 3 and idx.dim() == 3 and head.shape[:3] == idx.shape,
+            "concat_group expects head (B,M,K,Ch), points (B,N,C), idx (B,M,K)")
+    points = dev_tensor(points, torch.float32, "points")
+    idx = dev_tensor(idx, torch.int32, "idx")
+    return _ConcatGroup.apply(head, points, idx)
+
+
 class _GroupConcat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx, grouped_xyz, width, xyz_last):

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .grouping import group_point, knn_point
+from .grouping import concat_group, group_point, knn_point
 from .sampling import farthest_point_sample, gather_point
 from .mlp import BatchNormReLU, linear_nobias
 
@@ -246,7 +246,7 @@ class XConv(nn.Module):
         local = group_point(pts, idx) - qrs.unsqueeze(2)     # (B,P,K,3)  P' <- P - p
         f = self.lift1(self.lift0(local))                     # F_delta
         if fts is not None:
-            f = torch.cat([f, group_point(fts, idx)], dim=-1)  # F_* <- [F_delta, F]
+            f = concat_group(f, fts, idx)                      # F_* <- [F_delta, F]: gathered straight into the concat
         if self.with_x:
             x = self.x0(local.reshape(b, p, 1, k * 3)).reshape(b, p, k, k)
             x = self.x1(x).reshape(b, p, k, k)

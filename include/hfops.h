@@ -216,6 +216,13 @@ int hf_knn_point_sorted(int b, int n, int m, int k, const float *xyz1, const flo
  * [grouped_xyz (3), points[idx] (c), zeros], or with xyz_last != 0 the multi-scale module's order
  * [points[idx] (c), grouped_xyz (3), zeros] (pointnet_util.py:264); width >= 3 + c, width % 4 == 0.  Replaces
  * group_point + concat.  hf_group_concat_grad scatters the feature columns of grad_out back to grad_points (b, n, c). */
+/* group_point into / its gradient out of a column slice of wider rows: out (b, m, nsample, width)[..., col : col + c] =
+ * points[idx]; the other columns are not touched.  For concatenations whose other part is produced elsewhere (PointCNN's
+ * [lifted coordinates | gathered features], pointcnn.py:96-99).  16-byte copies when c, width, col are multiples of 4. */
+int hf_group_point_into(int b, int n, int c, int m, int nsample, int width, int col, const float *points, const int *idx,
+                        float *out, hf_stream_t stream);
+int hf_group_point_grad_from(int b, int n, int c, int m, int nsample, int width, int col, const float *grad_out,
+                             const int *idx, float *grad_points, hf_stream_t stream);
 int hf_group_concat(int b, int n, int c, int m, int nsample, int width, int xyz_last, const float *grouped_xyz,
                     const float *points, const int *idx, float *out, hf_stream_t stream);
 int hf_group_concat_grad(int b, int n, int c, int m, int nsample, int width, int xyz_last, const float *grad_out,

@@ -1659,3 +1659,24 @@ def test_knn_point_against_three_term_formula(hf, oracle_mod):
     assert same[clear].all(), "neighbour sets differ where the k-th gap exceeds the rounding of the three-term formula"
     # the kernel's own distances are the exact ones
     np.testing.assert_allclose(host(val), np.take_along_axis(d, idx.astype(np.int64), axis=2), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("c,ch", [(256, 64), (1, 64), (7, 5), (320, 128)])
+def test_concat_group_equals_cat_of_group_point(hf, c, ch):
+    """grouping.concat_group (group_point into a column slice of the concat buffer, gradient read in place) against
+    torch.cat([head, group_point(points, idx)], -1) and its autograd"""
+    from heterofusionrcnn_amd import grouping
+    g = torch.Generator().manual_seed(c * 31 + ch)
+    b, n, m, k = 2, 500, 130, 8
+    pts = torch.randn(b, n, c, generator=g).cuda().requires_grad_(True)
+    head = torch.randn(b, m, k, ch, generator=g).cuda().requires_grad_(True)
+    idx = torch.randint(0, n, (b, m, k), generator=g, dtype=torch.int32).cuda()
+    go = torch.randn(b, m, k, ch + c, generator=g).cuda()
+    out = grouping.concat_group(head, pts, idx)
+    out.backward(go)
+    p2, h2 = pts.detach().clone().requires_grad_(True), head.detach().clone().requires_grad_(True)
+    ref = torch.cat([h2, hf.group_point(p2, idx)], dim=-1)
+    ref.backward(go)
+    assert torch.equal(out, ref)
+    assert torch.equal(head.grad, h2.grad)
+    assert torch.allclose(pts.grad, p2.grad, rtol=1e-5, atol=1e-5)
