@@ -519,11 +519,13 @@ constexpr int kNmsListCap = 2048;   // entries per column block (a column that o
 
 // per-frame workspace of hf_oriented_nms:
 // [mask n*cb words][counts cb ints, padded][lists cb * kNmsListCap entries][transposed diagonal words, n][BoxPre table, n]
+// [next words, n: mask word (row, row block + 1)]
 __host__ __device__ inline size_t nms_ws_counts_offset(int n) { return (sizeof(unsigned long long) * static_cast<size_t>(n) * ((n + 63) / 64) + 255) & ~static_cast<size_t>(255); }
 __host__ __device__ inline size_t nms_ws_lists_offset(int n) { return nms_ws_counts_offset(n) + ((sizeof(int) * static_cast<size_t>((n + 63) / 64) + 255) & ~static_cast<size_t>(255)); }
 __host__ __device__ inline size_t nms_ws_diagt_offset(int n) { return nms_ws_lists_offset(n) + sizeof(NmsEntry) * static_cast<size_t>((n + 63) / 64) * kNmsListCap; }
 __host__ __device__ inline size_t nms_ws_boxpre_offset(int n) { return nms_ws_diagt_offset(n) + ((sizeof(unsigned long long) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255)); }
-__host__ __device__ inline size_t nms_ws_bytes(int n) { return nms_ws_boxpre_offset(n) + ((sizeof(BoxPre) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255)); }
+__host__ __device__ inline size_t nms_ws_nextw_offset(int n) { return nms_ws_boxpre_offset(n) + ((sizeof(BoxPre) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255)); }
+__host__ __device__ inline size_t nms_ws_bytes(int n) { return nms_ws_nextw_offset(n) + ((sizeof(unsigned long long) * static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255)); }
 
 // UPPER_ONLY = the form hf_oriented_nms launches: `mask` is the frame-0 workspace (stride ws_stride bytes per frame),
 // tiles below the diagonal are skipped, and every nonzero word right of the diagonal is also appended to the list of
@@ -620,7 +622,9 @@ __global__ __launch_bounds__(kNmsThreads, HF_NMS_THREADS >= 512 ? 8 : 4) void nm
     if (t < row_size) {
         const unsigned long long w = sh.words[t];
         mask[(static_cast<size_t>(row_t) * 64 + t) * col_blocks + col_t] = w;
-        if (UPPER_ONLY && col_t > row_t && w != 0ull) {
+        if (UPPER_ONLY && col_t == row_t + 1)   // the word next to the diagonal: the sweep's resolving wave adds these itself
+            reinterpret_cast<unsigned long long *>(ws + nms_ws_nextw_offset(n))[row_t * 64 + t] = w;
+        if (UPPER_ONLY && col_t > row_t + 1 && w != 0ull) {
             int *counts = reinterpret_cast<int *>(ws + nms_ws_counts_offset(n));
             NmsEntry *lists = reinterpret_cast<NmsEntry *>(ws + nms_ws_lists_offset(n));
             const int slot = atomicAdd(&counts[col_t], 1);
@@ -640,15 +644,17 @@ __global__ __launch_bounds__(kNmsThreads, HF_NMS_THREADS >= 512 ? 8 : 4) void nm
 // bev_iou.cpp:87-112 without the host.  One 1024-thread workgroup per frame walks the column blocks in order; the kept
 // bits of every block live in LDS.  The dense mask is 8 n^2/64 bytes (10 MB at 9000 boxes) of which almost every word is
 // zero, and ONE compute unit cannot stream it (measured: ~17 GB/s -> 0.25 ms for the upper triangle however deep the
-// prefetch).  So the mask kernel also files every nonzero word right of the diagonal under its column block, and
-// step blk reads that short list:
-//   gather   waves 1..15: the entries of column block blk (requested kSweepLead steps earlier, they depend on no
-//            decision): an entry whose row was kept adds its word to the block's removal word (an LDS atomic) -- the
-//            host loop's `remv[j] |= p[j]`, transposed;
-//   resolve  wave 0: lane l holds the TRANSPOSED diagonal word of box blk*64+l (which boxes of the block suppress it; the
-//            mask kernel writes it next to the mask).  kept = alive and no kept suppressor: iterated for the whole wave
-//            at once until nothing changes (one ballot per round, a round per link of the longest suppression chain)
-//            -- the host loop's `if (!(remv[nblock] & 1 << inblock))` without its 64 dependent steps.
+// prefetch).  So the mask kernel also files every nonzero word two or more blocks right of the diagonal under its
+// column block, writes the words NEXT to the diagonal to an array of their own and the diagonal tile transposed.
+// Step blk, one barrier per step:
+//   gather   waves 1..15: the entries of column block blk+1 (requested kSweepLead steps earlier, they depend on no
+//            decision); their rows lie in blocks <= blk-1, all decided: an entry whose row was kept adds its word to the
+//            block's removal word (an LDS atomic) -- the host loop's `remv[j] |= p[j]`, transposed;
+//   resolve  wave 0, meanwhile: the boxes kept in block blk-1 add their next words to block blk's removal word; then
+//            lane l holds the TRANSPOSED diagonal word of box blk*64+l (which boxes of the block suppress it).
+//            kept = alive and no kept suppressor: iterated for the whole wave at once until nothing changes (one ballot
+//            per round, a round per link of the longest suppression chain) -- the host loop's
+//            `if (!(remv[nblock] & 1 << inblock))` without its 64 dependent steps.
 // A column block whose list overflowed (> kNmsListCap nonzero words: thousands of boxes overlapping the same 64) is
 // gathered from the dense mask instead: every kept row so far is asked for its word of that column.
 // (Round 1 PULLED like that for every block: 0.95 ms of 1.14 ms.  Pushing kept rows into all later words, even with the
@@ -662,31 +668,33 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, int chu
                                                                   int *__restrict__ num_kept)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
     const int cb = (n + 63) / 64;
     // blockIdx.x = frame of a batched call
     const unsigned char *ws = ws_base + static_cast<size_t>(blockIdx.x) * ws_stride;
     const unsigned long long *mask = reinterpret_cast<const unsigned long long *>(ws);
     const int *counts = reinterpret_cast<const int *>(ws + nms_ws_counts_offset(n));
     const NmsEntry *lists = reinterpret_cast<const NmsEntry *>(ws + nms_ws_lists_offset(n));
+    const unsigned long long *diagt = reinterpret_cast<const unsigned long long *>(ws + nms_ws_diagt_offset(n));
+    const unsigned long long *nextw = reinterpret_cast<const unsigned long long *>(ws + nms_ws_nextw_offset(n));
     keep += static_cast<size_t>(blockIdx.x) * n;
     if (num_kept) num_kept += blockIdx.x;
-    unsigned long long *diagw = reinterpret_cast<unsigned long long *>(smem_raw);   // chunk_blocks * 64: diagonal words
-    unsigned long long *keptw = diagw + chunk_blocks * 64;                          // cb: kept bits per block
+    ull2 *dn = reinterpret_cast<ull2 *>(smem_raw);                                  // chunk_blocks * 64: (transposed diagonal word, next word)
+    unsigned long long *keptw = reinterpret_cast<unsigned long long *>(dn + chunk_blocks * 64);   // cb: kept bits per block
     unsigned long long *remv = keptw + cb;                                          // cb: removal word per block
     int *cnts = reinterpret_cast<int *>(remv + cb);                                 // cb: entries filed under the block
     __shared__ int kept_total;
     const int t = threadIdx.x;
     for (int w = t; w < cb; w += kSweepThreads) { remv[w] = 0ull; keptw[w] = 0ull; cnts[w] = counts[w]; }
     if (t == 0) kept_total = 0;
-    // every chunk_blocks steps all threads load the (transposed) diagonal words of the next chunk: wave 0 never waits
-    // for memory
-    const unsigned long long *diagt = reinterpret_cast<const unsigned long long *>(ws + nms_ws_diagt_offset(n));
+    // every chunk_blocks steps all threads load the word pairs of the next chunk: wave 0 never waits for memory
     auto load_chunk = [&](int c0) {
         const int i0 = c0 * 64, i1 = min(n, (c0 + chunk_blocks) * 64);
-        for (int i = i0 + t; i < i1; i += kSweepThreads) diagw[i - i0] = diagt[i];
+        for (int i = i0 + t; i < i1; i += kSweepThreads) dn[i - i0] = ull2{ diagt[i], (i >> 6) + 1 < cb ? nextw[i] : 0ull };
     };
     __syncthreads();
-    // Two loops with the same barriers: the resolving wave and the gatherers share nothing but LDS.
+    // Two loops with the same barriers (one per step): the resolving wave and the gatherers share nothing but LDS.
+    // Step s: wave 0 decides block s while the gatherers already collect column s+1 from the rows decided before.
     if (t < 64) {
         __builtin_amdgcn_s_setprio(3);
         for (int blk = 0; blk < cb; ++blk) {
@@ -694,12 +702,19 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, int chu
                 load_chunk(blk);
                 __syncthreads();
             }
-            __syncthreads();   // the gatherers are done with column blk
             const int i = blk * 64 + t;
             const int lim = min(64, n - blk * 64);
             const unsigned long long valid = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
+            const int slot = (blk % chunk_blocks) * 64 + t;
+            // the boxes kept in block blk-1 suppress through their NEXT word (the lists start two blocks to the right)
+            if (blk > 0 && ((keptw[blk - 1] >> t) & 1ull)) {
+                const unsigned long long nw = (blk % chunk_blocks) != 0 ? dn[slot - 64].y : nextw[i - 64];
+                if (nw != 0ull) atomicOr(&remv[blk], nw);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            asm volatile("" ::: "memory");
             // who (of this block) suppresses my box if kept: bits below my lane only
-            const unsigned long long killers = t < lim ? diagw[(blk % chunk_blocks) * 64 + t] : 0ull;
+            const unsigned long long killers = t < lim ? dn[slot].x : 0ull;
             const unsigned long long alive = ~remv[blk] & valid;   // not suppressed by boxes kept in earlier blocks
             // kept[l] = alive[l] and no kept killer: its unique solution is the fixed point of the whole-wave update below
             // (position l is final after l+1 rounds; a chain of suppressions is rarely deeper than a few boxes)
@@ -712,7 +727,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, int chu
             const int before = kept_total;
             if ((kb >> t) & 1ull) keep[before + __builtin_popcountll(kb & ((1ull << t) - 1ull))] = i;
             if (t == 0) { kept_total = before + __builtin_popcountll(kb); keptw[blk] = kb; }
-            __syncthreads();   // block blk is decided
+            __syncthreads();   // block blk is decided, column blk+1 has everything from blocks < blk
         }
     } else {
         const int u = t - 64;
@@ -727,39 +742,40 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, int chu
             return __builtin_amdgcn_raw_buffer_load_b128(rs, u * 16, 0, 0);
         };
         auto kept_row = [&](int row) -> bool { return (keptw[row >> 6] >> (row & 63)) & 1ull; };
-        u4v e0 = request(1), e1 = request(2), e2 = request(3), e3 = request(4);   // column 0 has no rows before it
+        u4v e0 = request(1), e1 = request(2), e2 = request(3), e3 = request(4);
         static_assert(kSweepLead == 4, "four entry registers rotate below");
+        // step blk gathers column blk+1: its entries come from row blocks <= blk-1, all decided
         auto gstep = [&](int blk, u4v &e) {
             if (blk % chunk_blocks == 0) {
                 load_chunk(blk);
                 __syncthreads();
             }
-            if (blk > 0) {
-                const int cnt = cnts[blk];   // uniform
+            const int col = blk + 1;
+            if (col < cb) {
+                const int cnt = cnts[col];   // uniform
                 unsigned long long acc = 0ull;
                 if (cnt <= kNmsListCap) {
                     const unsigned long long w0 = (static_cast<unsigned long long>(e.y) << 32) | e.x;
                     if (w0 != 0ull && kept_row(static_cast<int>(e.z))) acc = w0;
                     for (int k = u + kSweepGatherers; k < cnt; k += kSweepGatherers) {   // long lists: the rest, on demand
-                        const NmsEntry x = lists[static_cast<size_t>(blk) * kNmsListCap + k];
+                        const NmsEntry x = lists[static_cast<size_t>(col) * kNmsListCap + k];
                         if (kept_row(x.row)) acc |= x.word;
                     }
                 } else {
-                    // overflow: the dense mask, one word per kept row before this block
+                    // overflow: the dense mask, one word per kept row of the blocks before blk
                     for (int i = u; i < blk * 64; i += kSweepGatherers)
-                        if (kept_row(i)) acc |= mask[static_cast<size_t>(i) * cb + blk];
+                        if (kept_row(i)) acc |= mask[static_cast<size_t>(i) * cb + col];
                 }
-                if (acc != 0ull) atomicOr(&remv[blk], acc);   // few lanes hold anything: cheaper than a wave reduction first
+                if (acc != 0ull) atomicOr(&remv[col], acc);   // few lanes hold anything: cheaper than a wave reduction first
             }
-            e = request(blk + kSweepLead);
-            __syncthreads();   // column blk gathered
-            __syncthreads();   // block blk decided
+            e = request(col + kSweepLead);
+            __syncthreads();
         };
         for (int base = 0; base < cb; base += 4) {
-            gstep(base, e3);
-            if (base + 1 < cb) gstep(base + 1, e0);
-            if (base + 2 < cb) gstep(base + 2, e1);
-            if (base + 3 < cb) gstep(base + 3, e2);
+            gstep(base, e0);
+            if (base + 1 < cb) gstep(base + 1, e1);
+            if (base + 2 < cb) gstep(base + 2, e2);
+            if (base + 3 < cb) gstep(base + 3, e3);
         }
     }
     const int kept = kept_total;
@@ -846,8 +862,8 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
     if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return HF_EINVAL;   // the list entries are read 16 bytes at a time
     const int cb = (n + 63) / 64;
     // LDS: kept bits + removal words per block, and the diagonal words of a chunk of blocks (all of them up to 8192 boxes)
-    const int chunk_blocks = std::min(cb, 128);
-    const size_t lds = sizeof(unsigned long long) * (2 * static_cast<size_t>(cb) + 64 * static_cast<size_t>(chunk_blocks)) + sizeof(int) * static_cast<size_t>(cb);
+    const int chunk_blocks = std::min(cb, 64);   // (transposed diagonal, next) word pairs of 4096 boxes: 64 KB
+    const size_t lds = sizeof(unsigned long long) * (2 * static_cast<size_t>(cb) + 2 * 64 * static_cast<size_t>(chunk_blocks)) + sizeof(int) * static_cast<size_t>(cb);
     if (cb > 8192 || lds > 160 * 1024 - 256) return HF_EINVAL;   // n <= 524 288 boxes (pre_nms_size is 9000)
     hipStream_t st = as_stream(stream);
     unsigned char *ws = static_cast<unsigned char *>(workspace);

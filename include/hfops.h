@@ -140,8 +140,8 @@ int hf_nms_mask(const float *boxes, unsigned long long *mask, int boxes_num, flo
  * Workspace per frame (hf_oriented_nms_workspace(n) bytes, a multiple of 256; the base 16-byte aligned): the dense
  * mask (n * ceil(n/64) words), then -- each part padded to 256 bytes -- one counter per column block, one list of
  * 2048 (word, row) entries per column block (the nonzero words right of the diagonal, what the sweep reads), the
- * n transposed diagonal words, and an 80-byte table entry per box (cos / sin / corners, computed once per call).
- * About 1.5x the dense mask at n = 9000 (15.6 MB). */
+ * n transposed diagonal words, an 80-byte table entry per box (cos / sin / corners, computed once per call) and the n
+ * mask words next to the diagonal.  About 1.5x the dense mask at n = 9000 (15.6 MB). */
 size_t hf_oriented_nms_workspace(int n);
 int hf_oriented_nms(const float *boxes, int n, float thresh, int *keep, int *num_kept, void *workspace,
                     size_t workspace_bytes, hf_stream_t stream);

@@ -39,8 +39,8 @@ def test_version_and_strerror():
     assert L.hf_fps_workspace(8, 16384) == 0 and L.hf_fps_workspace(2, 20000) == 2 * 20000 * 4
     pad = lambda b: (b + 255) & ~255
     # dense mask + per-column-block counters + per-column-block lists (2048 x 16 bytes) + transposed diagonal words
-    # + the per-box table (80 bytes per box)
-    assert L.hf_oriented_nms_workspace(9000) == pad(9000 * 141 * 8) + pad(141 * 4) + 141 * 2048 * 16 + pad(9000 * 8) + pad(9000 * 80)
+    # + the per-box table (80 bytes per box) + the words next to the diagonal
+    assert L.hf_oriented_nms_workspace(9000) == pad(9000 * 141 * 8) + pad(141 * 4) + 141 * 2048 * 16 + pad(9000 * 8) + pad(9000 * 80) + pad(9000 * 8)
 
 
 def test_no_cpu_fallback():
