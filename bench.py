@@ -3,14 +3,17 @@
 
   python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-A "step" is one RPN train step (BASELINE.json: "KITTI frames/sec RPN train step") over one batch of synthetic
-KITTI-shaped frames resident in HBM: the PointNet++ backbone of hf/configs/rpn_cars_pointnet_paper.config (four
-multi-scale set-abstraction levels 16384 -> 4096 -> 1024 -> 512 -> 64, four feature-propagation levels, two fc layers),
-the foreground segmentation head, the bin-based box head, the target encoding and the focal / softmax / smooth-L1
-losses of hf/core/models/rpn_model.py, backward, Adam -- heterofusionrcnn_amd/rpn.py, fp32.  N > 1: one process per GPU
-(this script starts them itself when no launcher did), gradients all-reduced over RCCL by DistributedDataParallel
-(hf/experiments/mpi_run_training.sh + hvd.DistributedOptimizer, hf/core/trainer.py:71).  --workload stack selects the
-round-1 workload (BASELINE.json configs[1]: the single-scale SA+FP stack with a mean loss).
+A "step" is one RPN train step (BASELINE.json: "KITTI frames/sec RPN train step") of hf/configs/rpn_multiclass.config
+(BASELINE.json configs[3]) over one batch of synthetic KITTI-shaped frames resident in HBM: the PointCNN backbone (5 X-Conv +
+6 X-DeConv layers, fc 256/256), the projection of the points into the image and the gather of the image branch's feature map
+under them, path drop + 'concat' fusion, the segmentation head, the three-class bin-based box head, the target encoding and the
+focal / softmax / smooth-L1 losses of hf/core/models/rpn_model.py, backward (down to the gradient of the image feature map),
+Adam -- heterofusionrcnn_amd/rpn.py, fp32.  The image branch's VGG pyramid (a stock convolutional network, no custom op) is
+NOT run: its output, a (B,360,1200,32) feature map, is a resident synthetic input and the step ends with its gradient.
+The step is replayed from a captured hipGraph (heterofusionrcnn_amd/graph_step.py; --no-graph: eager launches).
+N > 1: one process per GPU (this script starts them itself when no launcher did), gradients averaged over RCCL
+(hf/experiments/mpi_run_training.sh + hvd.DistributedOptimizer, hf/core/trainer.py:71).  --workload rpn selects the
+PointNet++ configuration (rpn_cars_pointnet_paper.config), --workload stack the round-1 workload (BASELINE.json configs[1]).
 
 Rank 0 prints ONE JSON line: frames/s (whole job), plus
   roofline      the fused query_ball_point+group_point kernel at the headline shape
@@ -43,6 +46,29 @@ def kitti_uniform(rng, b, n):
     lo = np.array([-40.0, -5.0, 0.0], np.float32)
     hi = np.array([40.0, 3.0, 70.0], np.float32)
     return (lo + (hi - lo) * rng.random((b, n, 3), dtype=np.float32)).astype(np.float32)
+
+
+KITTI_P2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884]],
+                    np.float32)   # the left colour camera's projection matrix of a KITTI object frame
+IMG_H, IMG_W, IMG_C = 360, 1200, 32   # rpn_multiclass.config:14-15 and vgg_conv1[1] (:122), the width of pyramid_fusion1
+
+
+def kitti_frustum(rng, b, n, p2=KITTI_P2, h=IMG_H, w=IMG_W):
+    """uniform points of the KITTI extents that project INSIDE the image, as the reference's loader keeps them
+    (kitti_dataset.py:341-371 filters the cloud to the camera's field of view before sampling pc_sample_pts points)"""
+    out = np.empty((b, n, 3), np.float32)
+    for i in range(b):
+        got = 0
+        while got < n:
+            c = kitti_uniform(rng, 1, 4 * n)[0]
+            d = p2[2, 0] * c[:, 0] + p2[2, 1] * c[:, 1] + p2[2, 2] * c[:, 2] + p2[2, 3]
+            u = (p2[0, 0] * c[:, 0] + p2[0, 1] * c[:, 1] + p2[0, 2] * c[:, 2] + p2[0, 3]) / d
+            v = (p2[1, 0] * c[:, 0] + p2[1, 1] * c[:, 1] + p2[1, 2] * c[:, 2] + p2[1, 3]) / d
+            c = c[(d > 0.1) & (u >= 0) & (u < w) & (v >= 0) & (v < h)]
+            take = min(n - got, len(c))
+            out[i, got:got + take] = c[:take]
+            got += take
+    return out
 
 
 def rand_bev(rng, n):
@@ -347,21 +373,74 @@ def _cpu_chain(frames, seed, levels, fp_channels):
     return time.perf_counter() - t0, xyz0, xyzs
 
 
+def _pointcnn_plan(cfg):
+    """(K, data level, query level, gathered feature width) of every X-Conv / X-DeConv layer and the points per level, from the
+    PointCnnConfig (the same bookkeeping as pointcnn.PointCnnBackbone.__init__)"""
+    npts, chans = [N0], [cfg.in_channel]
+    enc = []
+    for li, (k, d, p, c) in enumerate(cfg.xconv):
+        same = p == -1 or (li > 0 and p == cfg.xconv[li - 1][2])
+        npts.append(npts[-1] if same else p)
+        enc.append((k * d, li, li + 1, chans[-1]))
+        chans.append(c + (c // 4 if (cfg.with_global and li == len(cfg.xconv) - 1) else 0))
+    dec, c_last = [], chans[-1]
+    for li, (k, d, pi, qi) in enumerate(cfg.xdconv):
+        dec.append((k * d, pi + 1, qi + 1, chans[pi + 1] if li == 0 else c_last))
+        c_last = cfg.xconv[qi][3]
+    return npts, enc, dec
+
+
+def _cpu_chain_pointcnn(frames, seed, img_c):
+    """the CPU oracle's custom-op chain of the rpn_multiclass step for `frames` frames: FPS + gather per encoder level, per
+    X-Conv / X-DeConv layer kNN + group (coordinates and features) + the group gradient, then the image projection + gather +
+    its scatter gradient"""
+    import oracle
+    from heterofusionrcnn_amd.pointcnn import PointCnnConfig
+    rng = np.random.default_rng(seed)
+    xyz0 = kitti_frustum(rng, frames, N0)
+    img = np.zeros((frames, IMG_H, IMG_W, img_c), np.float32) if img_c else None
+    npts, enc, dec = _pointcnn_plan(PointCnnConfig())
+    t0 = time.perf_counter()
+    pts = [xyz0]
+    for lvl in range(1, len(npts)):
+        cur = pts[-1]
+        pts.append(cur if npts[lvl] == cur.shape[1] else oracle.gather_point(cur, oracle.farthest_point_sample(npts[lvl], cur)))
+    for (k, di, qi, c) in enc + dec:
+        data, qrs = pts[di], pts[qi]
+        _, idx = oracle.knn_point(k, data, qrs)
+        oracle.group_point(data, idx)
+        f = np.zeros((frames, data.shape[1], c), np.float32)
+        g = oracle.group_point(f, idx)
+        oracle.group_point_grad(f.shape, idx, g)
+    if img_c:
+        calib = np.repeat(KITTI_P2[None], frames, 0)
+        out, pix = oracle.project_gather(xyz0, calib, img)
+        oracle.project_gather_grad(img.shape, pix, out)
+    return time.perf_counter() - t0, xyz0, pts
+
+
 def _cpu_chain_worker(args):
-    return _cpu_chain(*args)[0]
+    return (_cpu_chain_pointcnn if args[0] == "pointcnn" else _cpu_chain)(*args[1:])[0]
 
 
-def cpu_baseline(frames, levels, fp_channels):
-    """The CPU oracle's op chain for the same backbone (forward ops + the three backward ops), `frames` frames on ONE
+def cpu_baseline(frames, levels, fp_channels, pointcnn_img_c=None):
+    """The CPU oracle's op chain for the same backbone (forward ops + the backward ops of the path), `frames` frames on ONE
     core (the reference's CPU code is single-threaded), and the same chain on ALL host cores (one process per core, two
-    frames each).  The MLP GEMMs are not part of the custom-op path and are on neither side of this figure."""
+    frames each).  The dense layers are not part of the custom-op path and are on neither side of this figure.
+    pointcnn_img_c is not None: the chain of the rpn_multiclass step (_cpu_chain_pointcnn) instead of the SA / FP chain."""
     import multiprocessing as mp
     import oracle
-    dt, xyz0, xyzs = _cpu_chain(frames, 0, levels, fp_channels)
+    pointcnn = pointcnn_img_c is not None
+    if pointcnn:
+        dt, xyz0, xyzs = _cpu_chain_pointcnn(frames, 0, pointcnn_img_c)
+        what = ("FPS + gather per encoder level, kNN (K=8) + group(+grad) of the coordinates and features at each of the 5 X-Conv and "
+                "6 X-DeConv layers, image projection + gather(+grad)")
+    else:
+        dt, xyz0, xyzs = _cpu_chain(frames, 0, levels, fp_channels)
+        what = ("FPS, gather, ball query, group(+grad) at every SA level / scale, three_nn, three_interpolate(+grad) at every FP level")
     res = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frame(s) of the bench workload, custom-op chain only (FPS, gather, ball query, group(+grad) at every "
-                     "SA level / scale, three_nn, three_interpolate(+grad) at every FP level), oracle/hf_oracle.c, 1 thread, "
-                     "%.1f s" % (frames, dt)}
+           "sample": "%d frame(s) of the bench workload, custom-op chain only (%s), oracle/hf_oracle.c, 1 thread, %.1f s"
+                     % (frames, what, dt)}
     # the cores this process may use, at most 16 (the GPU box's CPU share for one GPU)
     ncore = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     try:
@@ -372,13 +451,16 @@ def cpu_baseline(frames, levels, fp_channels):
     per = 2
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(ncore) as pool:
-        pool.map(_cpu_chain_worker, [(per, 100 + i, levels, fp_channels) for i in range(ncore)])
+        jobs = [(("pointcnn", per, 100 + i, pointcnn_img_c) if pointcnn else ("sa_fp", per, 100 + i, levels, fp_channels))
+                for i in range(ncore)]
+        pool.map(_cpu_chain_worker, jobs)
     wall = time.perf_counter() - t0
     res["all_cores"] = {"value": round(per * ncore / wall, 3), "unit": "frames/s", "cores": ncore, "cpu_model": model,
                         "sample": "%d processes x %d frames, %.1f s wall (process start-up included)" % (ncore, per, wall)}
     # the reference's own CPU program for the headline pair, where oracle/_ref was built
     if oracle.ref_available("qbp"):
-        x, q = xyz0[:1], xyzs[1][:1]
+        x = kitti_uniform(np.random.default_rng(5), 1, N0)
+        q = oracle.gather_point(x, oracle.farthest_point_sample(SA[0][0], x))
         t1 = time.perf_counter()
         ridx = oracle.ref_query_ball_point(0.5, KNN, x, q)
         oracle.ref_group_point(x, ridx)
@@ -389,23 +471,29 @@ def cpu_baseline(frames, levels, fp_channels):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: 8 frames per GPU (the reference's own data-parallel mode: the per-rank batch of the config, "
-                         "rpn_multiclass.config:206); strong: a global batch of 8 frames split over the ranks")
-    ap.add_argument("--workload", choices=("rpn", "rpn_multiclass", "stack"), default="rpn",
-                    help="rpn: the RPN train step of rpn_cars_pointnet_paper.config (PointNet++ MSG backbone); rpn_multiclass: the "
-                         "RPN train step of rpn_multiclass.config (PointCNN backbone, three classes); stack: the round-1 workload, "
-                         "BASELINE.json configs[1] (single-scale SA+FP stack, mean loss)")
+                    help="weak: 8 frames per GPU (the reference's own data-parallel mode: a fixed per-rank batch, "
+                         "rpn_multiclass.config:206 + trainer.py:71); strong: a global batch of 8 frames split over the ranks")
+    ap.add_argument("--workload", choices=("rpn_multiclass", "rpn", "stack"), default="rpn_multiclass",
+                    help="rpn_multiclass: the RPN train step of rpn_multiclass.config (PointCNN backbone, image-feature fusion, three "
+                         "classes; BASELINE.json configs[3]); rpn: the RPN train step of rpn_cars_pointnet_paper.config (PointNet++ MSG "
+                         "backbone); stack: the round-1 workload, BASELINE.json configs[1] (single-scale SA+FP stack, mean loss)")
+    ap.add_argument("--img-channels", type=int, default=IMG_C,
+                    help="width of the image branch's feature map fed to the fusion of rpn_multiclass (0: point branch only)")
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the per-GPU batch (default: 8, or 8 / N with --scaling strong)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the step kernel by kernel (DistributedDataParallel for N > 1) "
+                                                            "instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-table", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the child runs reported in `extra` (other workload, 1 frame per GPU)")
     ap.add_argument("--no-prefetch", action="store_true", help="run the geometry ops inline instead of one step ahead")
     ap.add_argument("--prefetch-depth", type=int, default=2, help="batches of geometry in flight (one HIP stream each)")
     ap.add_argument("--prefetch-group", type=int, default=0,
                     help="batches whose geometry is computed in one launch (0 = the largest divisor of --steps up to 16, "
                          "so that the timed steps contain exactly as many geometry launches as they consume)")
-    ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the 1-core CPU leg (0: 4 for rpn_multiclass, else 24)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU test hook: the ranks join a gloo group and time a stand-in step (no HIP); exercises the "
                          "launcher / barrier / max-over-ranks / one-JSON-line plumbing without a GPU")
@@ -461,6 +549,21 @@ def stub_main(args):
     dp.shutdown(ctx)
 
 
+def _child_bench(extra_args, timeout=420):
+    """a side measurement in a CHILD process after the timed region (same contract: barrier, K timed steps, one JSON line)"""
+    import subprocess
+    try:
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-op-table", "--no-cpu-baseline", "--no-side-runs"] +
+                               list(extra_args), capture_output=True, text=True, timeout=timeout)
+        line = [l for l in child.stdout.splitlines() if l.startswith("{")][-1]
+        o = json.loads(line)
+        return {"frames_per_s": o["value"], "ms_per_step": o["ms_per_step"], "frames_per_gpu": o["config"]["frames_per_gpu"],
+                "host_enqueue_ms_per_step": o["config"]["host_enqueue_ms_per_step"], "hip_graph": o["config"]["hip_graph"],
+                "steps": o["steps"], "workload": o["config"]["workload"]}
+    except Exception as e:   # the headline line must not depend on a side measurement
+        return {"error": repr(e)[:200]}
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -490,18 +593,28 @@ def main():
     rpn_mod.query_ball_group = timer.wrap(rpn_mod.query_ball_group, headline)
     modules.query_ball_group = timer.wrap(modules.query_ball_group, headline)
 
-    per_gpu = B if args.scaling == "weak" else max(1, B // world)       # strong: a global batch of 8 split over the ranks
+    per_gpu = args.frames_per_gpu or (B if args.scaling == "weak" else max(1, B // world))   # strong: a global batch of 8 split over the ranks
     torch.manual_seed(1234)  # same initial weights on every rank (the reference broadcasts from rank 0)
     rng = np.random.default_rng(1000 + rank)                   # rank-sharded synthetic frames
-    xyz = torch.from_numpy(kitti_uniform(rng, per_gpu, N0)).cuda()
+    multiclass = args.workload == "rpn_multiclass"
+    img_c = args.img_channels if multiclass else 0
+    # rpn_multiclass: frames filtered to the camera's field of view as the reference's loader does (every point has a pixel)
+    xyz = torch.from_numpy(kitti_frustum(rng, per_gpu, N0) if multiclass else kitti_uniform(rng, per_gpu, N0)).cuda()
     intensity = torch.from_numpy(rng.uniform(-0.5, 0.5, (per_gpu, N0, 1)).astype(np.float32)).cuda()
+    inputs = {"xyz": xyz, "intensity": intensity}
+    levels = fp_channels = None
     if args.workload in ("rpn", "rpn_multiclass"):
-        cfg = rpn_mod.rpn_cars_pointnet_paper() if args.workload == "rpn" else rpn_mod.rpn_multiclass()
+        cfg = rpn_mod.rpn_cars_pointnet_paper() if args.workload == "rpn" else rpn_mod.rpn_multiclass(img_c)
         model = rpn_mod.RpnModel(cfg).cuda()
         # ground truth: 12 objects per frame on the road plane; the per-point class / box labels are made once, as the
         # reference's data loader makes them on the host (kitti_dataset.py:416-440)
         gt_boxes, gt_cls = rpn_mod.synthetic_ground_truth(rng, per_gpu, 12, cfg, ground_y=3.0)
-        label_cls, label_reg = rpn_mod.point_labels(xyz, torch.from_numpy(gt_boxes).cuda(), torch.from_numpy(gt_cls).cuda())
+        inputs["label_cls"], inputs["label_reg"] = rpn_mod.point_labels(xyz, torch.from_numpy(gt_boxes).cuda(), torch.from_numpy(gt_cls).cuda())
+        if img_c:
+            # the image branch's output (pyramid_fusion1 of img_vgg_pyramid.py: full resolution, vgg_conv1[1] channels): a resident
+            # synthetic feature map that requires a gradient -- the step ends where the VGG pyramid's backward pass would start
+            inputs["img_fts"] = torch.randn(per_gpu, IMG_H, IMG_W, img_c, device="cuda").requires_grad_(True)
+            inputs["calib"] = torch.from_numpy(KITTI_P2).cuda().repeat(per_gpu, 1, 1).contiguous()
         if args.workload == "rpn":
             levels = [(l.npoint, [(sc.radius, sc.nsample, sc.mlp[-1]) for sc in l.scales]) for l in cfg.sa]
             nl = len(cfg.sa)   # an FP level interpolates the features of the coarser level: the deepest SA output, then FP outputs
@@ -510,37 +623,55 @@ def main():
                         "512->64 (nsample 16/32), 4 FP levels, fc 256/256, seg head + bin-based box head (fc 512/512, 76 outputs), "
                         "targets + focal/softmax/smooth-L1 losses, fwd+bwd+Adam, fp32; image branch not part of the step")
         else:
-            levels, fp_channels = None, None   # the CPU leg of this workload is the kNN / FPS / group chain (cpu_baseline_pointcnn)
-            workload = ("RPN train step, hf/configs/rpn_multiclass.config point branch: PointCNN 5 xconv (K=8; 16384/4096/1024/256/64 "
-                        "points; C 256..1024, X-transformation, global branch) + 6 xdconv layers + fc 256/256, 3 classes, seg head + "
-                        "bin-based box head (fc 512/512, 3x76 outputs), targets + focal/softmax/smooth-L1 losses, fwd+bwd+Adam, fp32; "
-                        "image branch (VGG pyramid + concat fusion) not part of the step")
+            workload = ("RPN train step, hf/configs/rpn_multiclass.config: PointCNN 5 xconv (K=8; 16384/4096/1024/256/64 points; C 256.."
+                        "1024, X-transformation, global branch) + 6 xdconv layers + fc 256/256, 3 classes, seg head, " +
+                        ("projection of the points into the image + gather of the image feature map (B,%d,%d,%d) + path drop 0.9/0.9 + "
+                         "'concat' fusion, " % (IMG_H, IMG_W, img_c) if img_c else "") +
+                        "bin-based box head (fc 512/512, 3x76 outputs), targets + focal/softmax/smooth-L1 losses, fwd+bwd" +
+                        (" (incl. the scatter gradient of the image feature map)" if img_c else "") + "+Adam, fp32; " +
+                        ("the VGG pyramid that produces the image feature map is NOT run: the map is a resident synthetic input and "
+                         "its gradient the step's last output" if img_c else "image branch (VGG pyramid + concat fusion) not part of the step"))
+        loss_fn = None
     else:
         model = modules.PointnetSAFPStack(in_channel=1, sa=SA, fp=FP).cuda()
         levels = [(npoint, [(radius, ns, mlp[-1])]) for (npoint, radius, ns, mlp) in SA]
         fp_channels = [FP[1][-1], FP[0][-1], SA[-1][3][-1]]
         workload = ("SA+FP stack 16384->4096->1024->256, K=32, radii 0.5/1.0/2.0, fwd+bwd+Adam, mean loss, fp32 "
                     "(BASELINE.json configs[1])")
-    net = dp.wrap_model(model, ctx)                            # broadcast from rank 0 + gradient all-reduce (RCCL)
-    opt = torch.optim.Adam(net.parameters(), lr=dp.scaled_lr(1e-3, world), fused=True)  # optimizer_builder.py:105; one kernel for all tensors
+        loss_fn = lambda m, inp, geo: m(inp["xyz"], inp["intensity"], geometry=geo).mean()
 
+    from heterofusionrcnn_amd.graph_step import TrainStep, broadcast_parameters
     from heterofusionrcnn_amd.pipeline import GeometryPrefetcher, choose_group
+    use_graph = not args.no_graph
     group = args.prefetch_group or choose_group(args.steps)
     prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth, group=group)
+    lr = dp.scaled_lr(1e-3, world)                                   # optimizer_builder.py:105
+    train = None
+    if use_graph:
+        # one hipGraph launch per step: forward, losses, backward into ONE flat gradient buffer (+ Adam when there is a single
+        # rank); N > 1: one RCCL all-reduce of that buffer (hvd.DistributedOptimizer's average), then the fused Adam step
+        broadcast_parameters(model)                                  # hvd.broadcast_global_variables(0)
+        opt = torch.optim.Adam(model.parameters(), lr=lr, fused=True, capturable=True)
+        train = TrainStep(model, opt, inputs, model.geometry(xyz), world=world, graph=True, loss_fn=loss_fn)
+        net = model
+    else:
+        net = dp.wrap_model(model, ctx)                              # broadcast from rank 0 + bucketed gradient all-reduce (RCCL)
+        opt = torch.optim.Adam(net.parameters(), lr=lr, fused=True)  # one kernel for all tensors
+        eager_loss = loss_fn or (lambda m, inp, geo: _eager_rpn_loss(m, model, inp, geo))
 
     def step():
-        # the coordinate-only ops of the NEXT batch run on a side stream while this batch trains;
+        # the coordinate-only ops of the NEXT batches run on side streams while this batch trains;
         # each step consumes one geometry result and submits one: every step does the full work
         geo = None
         if prefetch is not None:
             geo = prefetch.get()
             prefetch.submit(xyz)
+        if use_graph:
+            return train(geometry=geo if geo is not None else model.geometry(xyz))
         opt.zero_grad(set_to_none=True)
-        if args.workload != "stack":
-            seg_logits, head = net(xyz, intensity, geometry=geo)
-            loss, _ = model.loss(xyz, seg_logits, head, label_cls, label_reg)
-        else:
-            loss = net(xyz, intensity, geometry=geo).mean()
+        if "img_fts" in inputs:
+            inputs["img_fts"].grad = None
+        loss = eager_loss(net, inputs, geo)
         loss.backward()
         opt.step()
         return loss
@@ -565,12 +696,15 @@ def main():
     dt = dp.max_over_ranks(time.perf_counter() - t0, ctx)
     timer.enabled = False
     assert torch.isfinite(loss).item(), "loss is not finite"
+    if "img_fts" in inputs:
+        g = inputs["img_fts"].grad
+        assert g is not None and torch.isfinite(g).all().item() and g.abs().sum().item() > 0, "no gradient reached the image feature map"
 
     result = None
     if rank == 0:
         frames = world * per_gpu * args.steps
         in_step_us = timer.mean_us()  # inside the timed steps: shares the device with the overlapped MLP kernels
-        xyz8 = xyz if per_gpu == B else torch.from_numpy(kitti_uniform(np.random.default_rng(1000), B, N0)).cuda()
+        xyz8 = torch.from_numpy(kitti_uniform(np.random.default_rng(1000), B, N0)).cuda()   # KITTI-extent uniform points
         k_us, n_burst = headline_kernel_burst(hf, xyz8)
         fused_bytes = ball_group_bytes(B, N0, SA[0][0], KNN)
         # algorithmic bytes of the two ops at their boundary = 24 641 536 B (the figure `frac` is computed from)
@@ -582,11 +716,15 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "frames_per_gpu": per_gpu, "global_batch": world * per_gpu, "parallelism": "dp%d" % world,
+                       "hip_graph": use_graph,
+                       "gradient_exchange": ("none (1 rank)" if world == 1 else
+                                             ("one RCCL all-reduce of the flat gradient buffer after the graph" if use_graph else
+                                              "DistributedDataParallel buckets overlapped with backward")),
                        "geometry_prefetch_depth": prefetch.depth if prefetch is not None else 0,
                        "geometry_prefetch_group": prefetch.group if prefetch is not None else 0,
                        "extra_untimed_alignment_steps": align,
-                       # host submission time per step: well below ms_per_step = the step is device-bound (a captured
-                       # graph of the feature half would not shorten it)
+                       # host time to submit a step (geometry launches, input copies, the graph launch); the rest of ms_per_step is
+                       # the host waiting for the device
                        "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3)},
             "roofline": {"kernel": "query_ball_point+group_point fused (hf_query_ball_group_xyz), B=8 N=16384 M=4096 K=32",
                          "bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
@@ -606,31 +744,33 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_op_table:
             result["extra"] = per_op_table(hf, xyz8)
-            if args.workload == "rpn":
-                # the other RPN configuration (rpn_multiclass.config: PointCNN backbone, three classes), measured by a CHILD
-                # process of this one after the timed region (same contract: barrier, K timed steps, one JSON line)
-                import subprocess
-                try:
-                    child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "rpn_multiclass", "--steps", "6",
-                                            "--warmup", "3", "--no-op-table", "--no-cpu-baseline"], capture_output=True, text=True,
-                                           timeout=300)
-                    line = [l for l in child.stdout.splitlines() if l.startswith("{")][-1]
-                    other = json.loads(line)
-                    result["extra"]["rpn_multiclass_train_step"] = {"frames_per_s": other["value"], "ms_per_step": other["ms_per_step"],
-                                                                    "workload": other["config"]["workload"]}
-                except Exception as e:   # the headline line must not depend on this side measurement
-                    result["extra"]["rpn_multiclass_train_step"] = {"error": repr(e)[:200]}
+        if not args.no_side_runs:
+            result.setdefault("extra", {})
+            train = prefetch = None                                  # release the graph's memory pool before the child runs
+            torch.cuda.empty_cache()
+            if multiclass:
+                # the per-rank shape of BASELINE config 4 (a batch of 8 over 8 GPUs = 1 frame per GPU), and the step without the graph
+                result["extra"]["rpn_multiclass_1_frame_per_gpu"] = _child_bench(["--frames-per-gpu", "1", "--steps", "32"])
+                result["extra"]["rpn_multiclass_eager_launches"] = _child_bench(["--no-graph", "--steps", "8"])
+                result["extra"]["rpn_pointnet_train_step"] = _child_bench(["--workload", "rpn", "--steps", "16"])
+            elif args.workload == "rpn":
+                result["extra"]["rpn_multiclass_train_step"] = _child_bench(["--workload", "rpn_multiclass", "--steps", "8"])
         if not args.no_cpu_baseline:
-            if levels is None:   # PointCNN: the CPU chain of the PointNet++ paper config is reported (same ops, other schedule)
-                pc = rpn_mod.rpn_cars_pointnet_paper()
-                levels = [(l.npoint, [(sc.radius, sc.nsample, sc.mlp[-1]) for sc in l.scales]) for l in pc.sa]
-                fp_channels = [pc.fp[len(pc.sa) - 2 - lvl][-1] for lvl in range(len(pc.sa) - 1)] + [1024]
-            result["cpu_baseline"] = cpu_baseline(args.cpu_frames, levels, fp_channels)
+            if multiclass:
+                result["cpu_baseline"] = cpu_baseline(args.cpu_frames or 4, None, None, pointcnn_img_c=img_c)
+            else:
+                result["cpu_baseline"] = cpu_baseline(args.cpu_frames or 24, levels, fp_channels)
     dp.shutdown(ctx)
     sys.stdout.flush()
     if rank == 0:
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     os.close(result_fd)
+
+
+def _eager_rpn_loss(net, model, inputs, geo):
+    seg_logits, head = net(inputs["xyz"], inputs["intensity"], geometry=geo, img_fts=inputs.get("img_fts"), calib=inputs.get("calib"))
+    loss, _ = model.loss(inputs["xyz"], seg_logits, head, inputs["label_cls"], inputs["label_reg"])
+    return loss
 
 
 if __name__ == "__main__":

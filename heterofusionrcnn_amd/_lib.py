@@ -72,6 +72,8 @@ _SIGNATURES = {
     "hf_linear_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 18 + [_vp, _sz, _vp],
     "hf_project_gather": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_project_gather_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "hf_fuse_concat": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "hf_fuse_concat_grad": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_bin_box_decode": [ctypes.c_longlong, _i] + [_vp] * 13 + [_f, _f, _vp, _vp],
     "hf_bin_box_encode": [ctypes.c_longlong, _i, _i] + [_vp] * 7 + [_f, _f, _f, _f] + [_vp] * 8 + [_vp],
     "hf_bin_head_decode": [ctypes.c_longlong, _i, _i, _i, _i] + [_vp] * 6 + [_f, _f, _vp, _vp, _vp],

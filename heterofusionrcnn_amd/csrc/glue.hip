@@ -213,6 +213,46 @@ __global__ void bin_box_encode_kernel(long long rows, int k, int rcnn, const flo
     }
 }
 
+
+// 'concat' fusion with path drop (rpn_model.py:515-546): out[row] = [a[row] * m0 | b[row] * m1], one pass instead of two
+// scaled copies and a concat.  masks = two floats on the device (the path-drop decision of this step), NULL = (1, 1).
+template <int VEC>
+__global__ void fuse_concat_kernel(long long rows, int c1, int c2, const float *__restrict__ a, const float *__restrict__ b,
+                                   const float *__restrict__ masks, float *__restrict__ out)
+{
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int cv = (c1 + c2) / VEC, c1v = c1 / VEC;
+    const float m0 = masks ? masks[0] : 1.0f, m1 = masks ? masks[1] : 1.0f;
+    const long long total = rows * cv;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / cv;
+        const int l = static_cast<int>(e - row * cv);
+        vec_t v;
+        if (l < c1v) v = *reinterpret_cast<const vec_t *>(a + row * c1 + l * VEC) * m0;
+        else v = *reinterpret_cast<const vec_t *>(b + row * c2 + (l - c1v) * VEC) * m1;
+        *reinterpret_cast<vec_t *>(out + e * VEC) = v;
+    }
+}
+
+template <int VEC>
+__global__ void fuse_concat_grad_kernel(long long rows, int c1, int c2, const float *__restrict__ g,
+                                        const float *__restrict__ masks, float *__restrict__ ga, float *__restrict__ gb)
+{
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int cv = (c1 + c2) / VEC, c1v = c1 / VEC;
+    const float m0 = masks ? masks[0] : 1.0f, m1 = masks ? masks[1] : 1.0f;
+    const long long total = rows * cv;
+    for (long long e = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long row = e / cv;
+        const int l = static_cast<int>(e - row * cv);
+        const vec_t v = *reinterpret_cast<const vec_t *>(g + e * VEC);
+        if (l < c1v) { if (ga) *reinterpret_cast<vec_t *>(ga + row * c1 + l * VEC) = v * m0; }
+        else if (gb) *reinterpret_cast<vec_t *>(gb + row * c2 + (l - c1v) * VEC) = v * m1;
+    }
+}
+
 static int glue_grid(long long items, int block)
 {
     long long g = (items + block - 1) / block;
@@ -256,6 +296,39 @@ HF_API int hf_project_gather_grad(int b, int p, int h, int w, int c, const float
     if (!grad_out || !pix) return HF_EINVAL;
     hipLaunchKernelGGL(project_gather_grad_kernel, dim3(glue_grid(nrows * c, 256)), dim3(256), 0, st, p, h, w, c, nrows,
                        grad_out, pix, grad_img);
+    return launch_status();
+}
+
+HF_API int hf_fuse_concat(long long rows, int c1, int c2, const float *a, const float *b, const float *masks, float *out,
+                          hf_stream_t stream)
+{
+    if (rows < 0 || c1 <= 0 || c2 <= 0) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    if (!a || !b || !out) return HF_EINVAL;
+    const bool vec4 = c1 % 4 == 0 && c2 % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
+    if (vec4)
+        hipLaunchKernelGGL((fuse_concat_kernel<4>), dim3(glue_grid(rows * ((c1 + c2) / 4), 256)), dim3(256), 0, as_stream(stream),
+                           rows, c1, c2, a, b, masks, out);
+    else
+        hipLaunchKernelGGL((fuse_concat_kernel<1>), dim3(glue_grid(rows * (c1 + c2), 256)), dim3(256), 0, as_stream(stream), rows,
+                           c1, c2, a, b, masks, out);
+    return launch_status();
+}
+
+HF_API int hf_fuse_concat_grad(long long rows, int c1, int c2, const float *grad_out, const float *masks, float *grad_a,
+                               float *grad_b, hf_stream_t stream)
+{
+    if (rows < 0 || c1 <= 0 || c2 <= 0) return HF_EINVAL;
+    if (rows == 0 || (!grad_a && !grad_b)) return HF_OK;
+    if (!grad_out) return HF_EINVAL;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_a) | reinterpret_cast<uintptr_t>(grad_b);
+    if (c1 % 4 == 0 && c2 % 4 == 0 && al % 16 == 0)
+        hipLaunchKernelGGL((fuse_concat_grad_kernel<4>), dim3(glue_grid(rows * ((c1 + c2) / 4), 256)), dim3(256), 0,
+                           as_stream(stream), rows, c1, c2, grad_out, masks, grad_a, grad_b);
+    else
+        hipLaunchKernelGGL((fuse_concat_grad_kernel<1>), dim3(glue_grid(rows * (c1 + c2), 256)), dim3(256), 0, as_stream(stream),
+                           rows, c1, c2, grad_out, masks, grad_a, grad_b);
     return launch_status();
 }
 

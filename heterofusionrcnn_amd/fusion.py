@@ -60,10 +60,57 @@ def project_gather(pts3d, calib, img_fts, return_pixels=False):
     return (out, pix) if return_pixels else out
 
 
-def fuse_point_image_features(pc_fts, proj_img_fts, method="concat", div=2.0):
-    """hf/core/models/rpn_model.py:537-548: "mean" = (pc + img) / div (equal widths), "concat" = [pc, img]"""
+def path_drop_masks(p_img, p_pc, random_values):
+    """create_path_drop_masks (rpn_model.py:1130-1193, rcnn_model.py:1264-1327): three coin flips decide which branch a
+    training step keeps.  random_values (3,) uniform in [0,1) on the device; returns a (2,) tensor [pc_mask, img_mask] of
+    0.0 / 1.0 on the device -- no host read, so the decision rides along in a captured graph.
+      img = r0 < p_img ; pc = r1 < p_pc ; both killed -> r2 > 0.5 keeps the image, r2 <= 0.5 keeps the points."""
+    r = random_values
+    img = (r[0] < p_img)
+    pc = (r[1] < p_pc)
+    both_dead = ~(img | pc)
+    img = torch.where(both_dead, r[2] > 0.5, img)
+    pc = torch.where(both_dead, r[2] <= 0.5, pc)
+    return torch.stack([pc, img]).to(torch.float32)
+
+
+class _FuseConcat(torch.autograd.Function):
+    """hf_fuse_concat (+ grad): [pc * mask_pc | img * mask_img] in one pass"""
+
+    @staticmethod
+    def forward(ctx, a, b, masks):
+        c1, c2 = a.shape[-1], b.shape[-1]
+        a2, b2 = a.reshape(-1, c1).contiguous(), b.reshape(-1, c2).contiguous()
+        out = torch.empty((a2.shape[0], c1 + c2), dtype=torch.float32, device=a.device)
+        check(_lib.lib().hf_fuse_concat(a2.shape[0], c1, c2, ptr(a2), ptr(b2), ptr(masks), ptr(out), stream_ptr()), "fuse_concat")
+        ctx.save_for_backward(masks) if masks is not None else ctx.save_for_backward()
+        ctx.shapes = (tuple(a.shape), tuple(b.shape))
+        return out.reshape(*a.shape[:-1], c1 + c2)
+
+    @staticmethod
+    def backward(ctx, g):
+        masks = ctx.saved_tensors[0] if ctx.saved_tensors else None
+        sa, sb = ctx.shapes
+        c1, c2 = sa[-1], sb[-1]
+        g = g.reshape(-1, c1 + c2).contiguous()
+        ga = torch.empty((g.shape[0], c1), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        gb = torch.empty((g.shape[0], c2), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().hf_fuse_concat_grad(g.shape[0], c1, c2, ptr(g), ptr(masks), ptr(ga), ptr(gb), stream_ptr()),
+              "fuse_concat_grad")
+        return (ga.reshape(sa) if ga is not None else None), (gb.reshape(sb) if gb is not None else None), None
+
+
+def fuse_point_image_features(pc_fts, proj_img_fts, method="concat", div=2.0, masks=None):
+    """hf/core/models/rpn_model.py:515-548: optional path drop (masks = path_drop_masks(...): [pc_mask, img_mask]), then
+    "mean" = (pc + img) / div (equal widths; div = img_mask + pc_mask under path drop) or "concat" = [pc, img]"""
     if method == "mean":
         require(pc_fts.shape[-1] == proj_img_fts.shape[-1], "mean fusion needs equal feature widths")
+        if masks is not None:
+            return (pc_fts * masks[0] + proj_img_fts * masks[1]) / (masks[0] + masks[1])
         return (pc_fts + proj_img_fts) / div
     require(method == "concat", "Invalid fusion method %r" % (method,))
+    if pc_fts.is_cuda and pc_fts.dtype == torch.float32 and proj_img_fts.dtype == torch.float32:
+        return _FuseConcat.apply(pc_fts, proj_img_fts, masks)
+    if masks is not None:
+        pc_fts, proj_img_fts = pc_fts * masks[0], proj_img_fts * masks[1]
     return torch.cat([pc_fts, proj_img_fts], dim=-1)

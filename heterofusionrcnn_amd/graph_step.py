@@ -1,0 +1,165 @@
+"""The RPN train step as ONE HIP graph launch (forward + losses + backward [+ Adam]).
+
+The step of hf/core/trainer.py:71-73,150-190 (session.run of train_op: forward, losses, gradients, the Horovod-averaged
+gradient, Adam) is ~1400 kernel launches for the PointCNN configuration.  Enqueued one by one from Python they cost the host
+27 ms per step -- more than the device needs at the reference's own per-rank batch of 2 (rpn_multiclass.config:206) or at one
+frame per GPU (BASELINE config 4: a batch of 8 over 8 GPUs).  Here the step is captured once into a hipGraph and replayed:
+
+  static slots     the frames (xyz, intensity, image feature map, calibration, labels) and the coordinate-only geometry
+                   (sampled points, neighbour tables: pipeline.GeometryPrefetcher computes it ahead on side streams) live in
+                   fixed buffers; a step copies its inputs in (one foreach copy) and replays the graph;
+  flat gradients   every parameter's .grad is a view into ONE buffer, zeroed inside the graph: with several ranks the
+                   gradient exchange is one RCCL all-reduce of that buffer (hvd.DistributedOptimizer averages gradients,
+                   trainer.py:71), followed by the fused Adam step; with one rank Adam is part of the graph;
+  random numbers   dropout and the path-drop coin flips draw from the device generator, whose Philox offset PyTorch
+                   advances per replay: every step sees fresh masks, as in eager mode (tests/test_graph_step.py).
+
+No work is skipped or cached: a replay launches exactly the kernels the eager step launches.
+"""
+import torch
+import torch.distributed as dist
+
+
+def tree_tensors(obj, out=None):
+    """the tensors of a nested dict / list / tuple structure, in a fixed order"""
+    out = [] if out is None else out
+    if isinstance(obj, torch.Tensor):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for k in sorted(obj):
+            tree_tensors(obj[k], out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            tree_tensors(v, out)
+    return out
+
+
+def tree_map(obj, fn):
+    if isinstance(obj, torch.Tensor):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: tree_map(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(tree_map(v, fn) for v in obj)
+    return obj
+
+
+class FlatGrads:
+    """.grad of every parameter as a view into one contiguous buffer (gradient_as_bucket_view with a single bucket)"""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, world):
+        """hvd.DistributedOptimizer: the average over the replicas, one collective for the whole model"""
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / world)
+
+
+def broadcast_parameters(module, src=0):
+    """hvd.broadcast_global_variables(0) (trainer.py:73,144): rank 0's parameters and buffers to everyone"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src)
+
+
+class TrainStep:
+    """One RPN train step.  graph=False: the eager step (flat gradients, explicit all-reduce); graph=True: the same step
+    replayed from a captured hipGraph.
+
+      step = TrainStep(model, opt, inputs, geometry, world=..., graph=True)
+      loss = step(geometry=geo)          # inputs are the static tensors given at construction unless passed again
+
+    `inputs`: dict with xyz, intensity, label_cls, label_reg and optionally img_fts, calib.  `loss_fn(model, inputs, geometry)`
+    returns the scalar loss (default: RpnModel forward + RpnModel.loss)."""
+
+    def __init__(self, model, optimizer, inputs, geometry, world=1, graph=True, loss_fn=None, warmup=3):
+        self.model, self.opt, self.world = model, optimizer, world
+        self.loss_fn = loss_fn or _rpn_loss
+        self.grads = FlatGrads(model.parameters())
+        self.inputs = dict(inputs)
+        self.geometry = tree_map(geometry, lambda t: t.clone())       # static slots
+        self._geo_slots = tree_tensors(self.geometry)
+        self.graph = None
+        self.loss = None
+        self.opt_in_graph = world == 1
+        if graph:
+            self._capture(warmup)
+
+    # ------------------------------------------------------------------ pieces
+    def _forward_backward(self):
+        self.grads.zero()
+        img = self.inputs.get("img_fts")
+        if img is not None and img.requires_grad:
+            img.grad = None                                           # a leaf outside the model: backward stores, never adds
+        loss = self.loss_fn(self.model, self.inputs, self.geometry)
+        loss.backward()
+        return loss.detach()
+
+    def _finish(self):
+        self.grads.all_reduce_mean(self.world)
+        self.opt.step()
+
+    def _capture(self, warmup):
+        # PyTorch's recipe: a few eager iterations on a side stream (lazy initialisations, allocator warm-up, optimizer
+        # state), then capture on that stream
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._forward_backward()
+                self._finish()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._forward_backward()
+            if self.opt_in_graph:
+                self.opt.step()
+
+    # ------------------------------------------------------------------ a step
+    def load(self, geometry=None, **inputs):
+        """copy this step's inputs into the static slots (device-to-device, no synchronisation)"""
+        dst, src = [], []
+        if geometry is not None:
+            new = tree_tensors(geometry)
+            assert len(new) == len(self._geo_slots), "geometry structure changed"
+            dst += self._geo_slots
+            src += new
+        for k, v in inputs.items():
+            if v is not None and v is not self.inputs[k]:
+                dst.append(self.inputs[k] if not self.inputs[k].requires_grad else self.inputs[k].detach())
+                src.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def __call__(self, geometry=None, **inputs):
+        self.load(geometry, **inputs)
+        if self.graph is None:
+            self.loss = self._forward_backward()
+            self._finish()
+        else:
+            self.graph.replay()
+            if not self.opt_in_graph:
+                self._finish()
+        return self.loss
+
+
+def _rpn_loss(model, inputs, geometry):
+    seg_logits, head = model(inputs["xyz"], inputs["intensity"], geometry=geometry, img_fts=inputs.get("img_fts"),
+                             calib=inputs.get("calib"))
+    loss, _ = model.loss(inputs["xyz"], seg_logits, head, inputs["label_cls"], inputs["label_reg"])
+    return loss

@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import box_codec
-from .fusion import fuse_point_image_features, project_gather
+from .fusion import fuse_point_image_features, path_drop_masks, project_gather
 from .modules import PointnetFPModule, PointnetSAModule, SharedMLPLayer
 from .grouping import group_concat, group_point, query_ball_group
 from .sampling import farthest_point_sample, gather_point
@@ -69,6 +69,7 @@ class RpnConfig:
     pointcnn: Optional[object] = None                                      # pointcnn.PointCnnConfig for backbone 'pointcnn'
     fusion: str = "none"                                                   # 'mean' | 'concat' | 'none' (no image branch)
     img_channels: int = 0
+    path_drop: Tuple[float, float] = (1.0, 1.0)                            # keep probabilities [image, points]; (1, 1) = off
     seg_loss_weight: float = 100.0
     cls_loss_weight: float = 1.0
     reg_loss_weight: float = 1.0
@@ -116,11 +117,13 @@ def rpn_stack_config2() -> RpnConfig:
 
 def rpn_multiclass(img_channels: int = 0) -> RpnConfig:
     """hf/configs/rpn_multiclass.config: the PointCNN extractor (:62-118), three classes with their own search ranges
-    (:20-36), 'concat' fusion with the image branch's features when a feature map is supplied (img_channels > 0)."""
+    (:20-36), 'concat' fusion (:21) with the image branch's features and path drop 0.9 / 0.9 (:57) when a feature map is
+    supplied (img_channels > 0; the VGG pyramid of :120-128 ends in vgg_conv1[1] = 32 channels at full resolution)."""
     from .pointcnn import PointCnnConfig
     import dataclasses
     base = RpnConfig(name="rpn_multiclass", backbone="pointcnn", pointcnn=PointCnnConfig(),
-                     fusion="concat" if img_channels else "none", img_channels=img_channels)
+                     fusion="concat" if img_channels else "none", img_channels=img_channels,
+                     path_drop=(0.9, 0.9) if img_channels else (1.0, 1.0))
     heads = rpn_multiclass_heads(base)
     return dataclasses.replace(heads, name="rpn_multiclass")
 
@@ -275,7 +278,10 @@ class RpnHeads(nn.Module):
         seg_logits = linear_narrow(pc_fts, self.seg.weight, self.seg.bias)   # (B,P,K+1)
         x = pc_fts
         if self.cfg.fusion != "none":
-            x = fuse_point_image_features(pc_fts, proj_img_fts, self.cfg.fusion)
+            masks = None
+            if self.training and tuple(self.cfg.path_drop) != (1.0, 1.0):      # rpn_model.py:515-535
+                masks = path_drop_masks(self.cfg.path_drop[0], self.cfg.path_drop[1], torch.rand(3, device=pc_fts.device))
+            x = fuse_point_image_features(pc_fts, proj_img_fts, self.cfg.fusion, masks=masks)
         x = x.reshape(b * p, -1)
         for layer, rate in zip(self.fc, self.drop):
             x = F.dropout(layer(x), p=rate, training=self.training)     # tf.layers.dropout(rate)

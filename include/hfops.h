@@ -327,6 +327,14 @@ int hf_project_gather(int b, int p, int h, int w, int c, const float *pts, const
                       int *pix, hf_stream_t stream);
 int hf_project_gather_grad(int b, int p, int h, int w, int c, const float *grad_out, const int *pix, float *grad_img,
                            hf_stream_t stream);
+/* The 'concat' fusion of the RPN / RCNN with its path drop (hf/core/models/rpn_model.py:515-546, rcnn_model.py:560-590):
+ * out (rows, c1+c2) = [a * masks[0] | b * masks[1]]; masks = two floats ON THE DEVICE (this step's path-drop decision,
+ * create_path_drop_masks, rpn_model.py:1130-1193) or NULL for (1, 1).  _grad: grad_a = grad_out[:, :c1] * masks[0],
+ * grad_b = grad_out[:, c1:] * masks[1]; either may be NULL. */
+int hf_fuse_concat(long long rows, int c1, int c2, const float *a, const float *b, const float *masks, float *out,
+                   hf_stream_t stream);
+int hf_fuse_concat_grad(long long rows, int c1, int c2, const float *grad_out, const float *masks, float *grad_a,
+                        float *grad_b, hf_stream_t stream);
 /* hf/core/bin_based_box3d_encoder.py:9-139 (tf_decode) for `rows` reference points x k classes: rows = B*p in the RPN
  * (ref_theta NULL = the constant 0), the RoI count in the RCNN.  Per (row, class) inputs are (rows, k[, 3]) arrays;
  * ss / deltas (k,) the per-class XZ search range and bin length; boxes (rows, k, 7) = [x, y, z, l, w, h, ry]. */
