@@ -145,8 +145,10 @@ def time_op_stats(fn, iters=30, warm=5):
 
 
 def batched_kernel_burst(hf, clouds=80, launches=100):
-    """the same kernel on the batched shape the train step launches it with (the clouds of a geometry group in one launch),
-    alone on the device: per-cloud cost and fraction of the roofline when the fixed launch cost is amortised"""
+    """the same op on the batched shape the train step launches it with (the clouds of a geometry group in one call), alone on
+    the device, through hf_query_ball_group_xyz_ws with a workspace as the Python layer calls it: at this size the library
+    builds the cell structure once per cloud (ballquery_sorted.hip: two kernels per call); the single-launch kernel is timed
+    next to it"""
     from heterofusionrcnn_amd import _lib
     L = _lib.lib()
     m = SA[0][0]
@@ -155,23 +157,33 @@ def batched_kernel_burst(hf, clouds=80, launches=100):
     idx = torch.empty((clouds, m, KNN), dtype=torch.int32, device="cuda")
     cnt = torch.empty((clouds, m), dtype=torch.int32, device="cuda")
     grouped = torch.empty((clouds, m, KNN, 3), dtype=torch.float32, device="cuda")
+    nbytes = L.hf_ball_query_workspace(clouds, N0)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    args = (clouds, N0, m, SA[0][1], KNN, xyz.data_ptr(), new_xyz.data_ptr(), 1, idx.data_ptr(), cnt.data_ptr(),
-            grouped.data_ptr(), st)
-    for _ in range(5):
-        assert L.hf_query_ball_group_xyz(*args) == 0
-    torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(launches):
-        L.hf_query_ball_group_xyz(*args)
-    e1.record()
-    torch.cuda.synchronize()
-    us = 1e3 * e0.elapsed_time(e1) / launches
-    nbytes = SURVEY_TWO_OP_BYTES * clouds / B
-    return {"clouds_per_launch": clouds, "avg_launch_us": round(us, 2), "us_per_cloud": round(us / clouds, 3),
-            "achieved_GBs": round(nbytes / (us * 1e-6) / 1e9, 1), "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    out = {"clouds_per_launch": clouds}
+    nbytes_alg = SURVEY_TWO_OP_BYTES * clouds / B
+    for name, variant in (("auto", 0), ("single_launch_cell_kernel", 1)):
+        args = (variant, clouds, N0, m, SA[0][1], KNN, xyz.data_ptr(), new_xyz.data_ptr(), 1, idx.data_ptr(), cnt.data_ptr(),
+                grouped.data_ptr(), ws.data_ptr(), nbytes, st)
+        for _ in range(5):
+            assert L.hf_query_ball_group_xyz_ws(*args) == 0
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            L.hf_query_ball_group_xyz_ws(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / launches
+        r = {"avg_call_us": round(us, 2), "us_per_cloud": round(us / clouds, 3),
+             "achieved_GBs": round(nbytes_alg / (us * 1e-6) / 1e9, 1), "frac": round(nbytes_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        if name == "auto":
+            out.update(r)
+            out["kernels_per_call"] = "bq_build_kernel + bq_query_kernel (cell-sorted path)"
+        else:
+            out[name] = r
+    return out
 
 
 def headline_kernel_burst(hf, xyz, launches=200):

@@ -12,7 +12,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libhfops.so")
+# HFOPS_LIBRARY: load another build of the same ABI (scripts/probes/build_diag.sh makes one with -DHF_DIAG, whose kernels
+# honour the diagnostic knobs the product library compiles out); read once at import, never on a launch path
+LIB_PATH = os.environ.get("HFOPS_LIBRARY") or os.path.join(CSRC, "libhfops.so")
 
 HF_OK, HF_EINVAL, HF_EHIP, HF_EWORKSPACE = 0, -1, -2, -3
 
@@ -21,6 +23,7 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 # name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/hfops.h
 _SIGNATURES = {
     "hf_farthest_point_sample": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "hf_farthest_point_sample_variant": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_fps_workspace": [_i, _i],
     "hf_fps_onchip_limit": [],
     "hf_gather_point": [_i, _i, _i, _vp, _vp, _vp, _vp],
@@ -29,6 +32,8 @@ _SIGNATURES = {
     "hf_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "hf_ball_query_workspace": [_i, _i],
+    "hf_query_ball_group_xyz_ws": [_i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_knn_point": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_knn_workspace": [_i, _i],
     "hf_knn_point_sorted": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -91,6 +96,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {
     "hf_fps_workspace": _sz,
+    "hf_ball_query_workspace": _sz,
     "hf_oriented_nms_workspace": _sz,
     "hf_bn_workspace": _sz,
     "hf_three_nn_workspace": _sz,

@@ -39,11 +39,10 @@
 // Results do not depend on the cell geometry, on the arrival order of the atomics or on the chunking: the hit
 // set is decided by the same `s < T` on every candidate and the order by the data index alone.
 #include <math.h>
-#include <stdlib.h>
 
 #include <type_traits>
 
-#include "hf_common.h"
+#include "bq_common.h"
 
 namespace hf {
 
@@ -68,21 +67,6 @@ struct CellShared {
     int exh;                            // exhaustive mode (a query's padded box may span three cells)
     int flag;                           // block-wide AND (all_threads)
 };
-
-// Points and grouped rows are 12-byte elements.  They go through raw buffer accesses of exactly 96 bits (clang widens a
-// plain vec3 load / store to 16 bytes: the store would clobber the next element, the load could leave the tensor),
-// whose range check also returns zeros / drops the store past the end, so no index needs clamping.
-typedef unsigned u3v __attribute__((ext_vector_type(3)));
-struct P3 { float x, y, z; };
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, static_cast<int>(bytes), 0x00020000);
-}
-__device__ __forceinline__ P3 load_p3(__amdgpu_buffer_rsrc_t r, unsigned elem)
-{
-    const u3v v = __builtin_amdgcn_raw_buffer_load_b96(r, static_cast<int>(elem * 12u), 0, 0);
-    return P3{ __uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z) };
-}
 
 // LDS word at a byte offset from the start of the workgroup's allocation.  The kernel has no static LDS object, so
 // its dynamic region starts at 0 (cell_launch checks the attribute): the address needs no base added per access.
@@ -124,29 +108,6 @@ __device__ unsigned long long g_qbp_stamps[4096 * 16];
 #define HF_STAMP_LAST(i) do { } while (0)
 #define HF_STAMP_REAL(i, thr) do { } while (0)
 #endif
-
-// a * b + c on the low 24 bits of a and b: one full-rate instruction (hipcc turns __umul24 + add into the
-// quarter-rate 64-bit v_mad_u64_u32 here)
-__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c)
-{
-    unsigned r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// stores in three flavours: SM = 0 plain, 1 nontemporal, 2 write-through (sc0 sc1)
-template <int SM> struct StoreAux { static constexpr int value = SM == 1 ? 2 : (SM == 2 ? 17 : 0); };
-template <int SM>
-__device__ __forceinline__ void store_i32(__amdgpu_buffer_rsrc_t r, unsigned elem, int v)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(static_cast<unsigned>(v), r, static_cast<int>(elem * 4u), 0, StoreAux<SM>::value);
-}
-template <int SM>
-__device__ __forceinline__ void store_p3(__amdgpu_buffer_rsrc_t r, unsigned elem, float x, float y, float z)
-{
-    const u3v v = { __float_as_uint(x), __float_as_uint(y), __float_as_uint(z) };
-    __builtin_amdgcn_raw_buffer_store_b96(v, r, static_cast<int>(elem * 12u), 0, StoreAux<SM>::value);
-}
 
 template <bool GROUP, int SM, int NT, bool A4>
 __global__ __launch_bounds__(NT) void qbp_cell_kernel(int n, int m, int qpw, int glog, float radius,
@@ -589,12 +550,6 @@ static size_t cell_lds_bytes(int nsample, int qpw, int cap, int nt)
            sizeof(int) * (static_cast<size_t>(qpw) * rs + qpw + 2 * nt);
 }
 
-static int cell_env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e && e[0] ? atoi(e) : dflt;
-}
-
 template <bool GRP, int SM, int NT, bool A4>
 static int cell_launch(dim3 grid, size_t lds, hipStream_t st, int n, int m, int qpw, int glog, float radius, float thresh,
                         float inv_cs, int nsample, int ns_shift, int cap, int stop, const float *xyz1, const float *xyz2,
@@ -625,24 +580,24 @@ int launch_ball_query_cell(int b, int n, int m, float radius, float thresh, int 
     if (nsample > 128 || !(radius < 3.0e18f) || !(radius > 1.0e-18f) || b > 65535 || n > (1 << kCellIdxBits)) return HF_EINVAL;
     // workgroup size: 1024 threads, 16 points each.  HF_QBP_NT=512 selects the 8-wave form with 32 points per thread
     // (diagnostics only: measured slower, profiles/r02_qbp_cell_notes.md)
-    const int nt = cell_env_int("HF_QBP_NT", 1024) == 512 ? 512 : 1024;
+    const int nt = HF_DIAG_INT("HF_QBP_NT", 1024) == 512 ? 512 : 1024;
     // queries per workgroup: rows of nsample ints in LDS; G = nt / qpw lanes per query, 4 <= G <= 64
     int qpw = nsample <= 32 ? 128 : (nsample <= 64 ? 64 : 32);
     // batched launches (the clouds of a geometry group): 256 queries per workgroup halve the per-query share of the cloud
     // scan as soon as that still fills every CU (80 clouds: 91.8 -> 69.1 us; 8 clouds: 11.7 -> 16.4 us, so not there)
     if (nsample <= 32 && nt == 1024 && static_cast<long long>(b) * div_up(m, 256) >= kNumCU) qpw = 256;
     while (qpw > nt / 64 && static_cast<long long>(b) * div_up(m, qpw) < kNumCU) qpw >>= 1;
-    qpw = cell_env_int("HF_QBP_QPW", qpw);            // diagnostics only
+    qpw = HF_DIAG_INT("HF_QBP_QPW", qpw);            // diagnostics only
     if (qpw < nt / 64 || qpw > 256 || qpw > nt / 4 || (qpw & (qpw - 1))) return HF_EINVAL;
     int glog = 0;
     while ((nt >> glog) > qpw) ++glog;
-    const int cap = cell_env_int("HF_QBP_CAP", 2048);  // diagnostics only (>= 2048: one dense chunk always fits)
+    const int cap = HF_DIAG_INT("HF_QBP_CAP", 2048);  // diagnostics only (>= 2048: one dense chunk always fits)
     if (cap < kCellChunk || cap >= (1 << kCellSlotBits)) return HF_EINVAL;
     if (div_up(m, qpw) > 65535) return HF_EINVAL;
-    const int stop = cell_env_int("HF_QBP_STOP", 0);   // diagnostics only: early exit after a phase (outputs invalid)
+    const int stop = HF_DIAG_INT("HF_QBP_STOP", 0);   // diagnostics only: early exit after a phase (outputs invalid)
     // stores: write-through when the whole grid is one round of workgroups (11.07 vs 11.27 us at 8 clouds), non-temporal
     // for larger grids (69.6 vs 71.9 us at 80 clouds); HF_QBP_STORE = 0 plain / 1 non-temporal / 2 write-through: diagnostics
-    const int sm = cell_env_int("HF_QBP_STORE", static_cast<long long>(b) * div_up(m, qpw) <= kNumCU ? 2 : 1);
+    const int sm = HF_DIAG_INT("HF_QBP_STORE", static_cast<long long>(b) * div_up(m, qpw) <= kNumCU ? 2 : 1);
     const size_t lds = cell_lds_bytes(nsample, qpw, cap, nt);
     const float inv_cs = 1.0f / (2.2f * radius);   // cell width 2.2 radius >= 2 (radius + pad)
     int ns_shift = -1;
@@ -650,7 +605,7 @@ int launch_ball_query_cell(int b, int n, int m, float radius, float thresh, int 
     dim3 grid(b, div_up(m, qpw));
     // four consecutive points per thread through 16-byte loads when every cloud starts on a 16-byte boundary
     // (HF_QBP_A4=0: diagnostics, the 12-byte form)
-    const bool a4 = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(xyz1) % 16 == 0) && cell_env_int("HF_QBP_A4", 1) != 0;
+    const bool a4 = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(xyz1) % 16 == 0) && HF_DIAG_INT("HF_QBP_A4", 1) != 0;
 #define HF_CELL_ARGS grid, lds, st, n, m, qpw, glog, radius, thresh, inv_cs, nsample, ns_shift, cap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped
 #define HF_CELL_DISPATCH(GRP, SMODE)                                                                                   \
     do {                                                                                                              \

@@ -15,7 +15,6 @@
 // The clip itself follows the reference operation by operation (fp32, no contraction); cos/sin
 // are evaluated once per box per pair-side (cos(-a) == cos(a), sin(-a) == -sin(a) exactly).
 #include <math.h>
-#include <stdlib.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -808,8 +807,7 @@ HF_API int hf_compute_bev_iou(int num_a, const float *boxes_a, int num_b, const 
     if (!ans_overlap && !ans_iou) return HF_OK;
     const int gy = (num_a + kIouRows - 1) / kIouRows, gx = (num_b + 63) / 64;
     tile_lds_attr(&bev_iou_kernel, sizeof(IouShared));
-    const char *stop_env = getenv("HF_BEV_STOP");   // diagnostics only: early exit after a phase (outputs invalid)
-    const int stop = stop_env && stop_env[0] ? atoi(stop_env) : 0;
+    const int stop = HF_DIAG_INT("HF_BEV_STOP", 0);   // diagnostic builds only: early exit after a phase (outputs invalid)
     if ((ans_overlap && reinterpret_cast<uintptr_t>(ans_overlap) % 16 != 0) || (ans_iou && reinterpret_cast<uintptr_t>(ans_iou) % 16 != 0))
         return HF_EINVAL;   // the outputs are written with 16-byte stores (every allocator returns at least that alignment)
     if (gy > 65535) {
@@ -877,8 +875,7 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
                        reinterpret_cast<unsigned long long *>(ws), ws_stride);
     rc = launch_status();
     if (rc != HF_OK) return rc;
-    const char *nms_stop = getenv("HF_NMS_STOP");   // diagnostics only: 1 = mask kernel alone (keep[] is not written)
-    if (nms_stop && nms_stop[0] == '1') return HF_OK;
+    if (HF_DIAG_INT("HF_NMS_STOP", 0) == 1) return HF_OK;   // diagnostic builds only: mask kernel alone (keep[] is not written)
     static size_t sweep_lds_allowed = 48 * 1024;   // raise the dynamic-LDS limit once, not on every launch
     if (lds > sweep_lds_allowed) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -20,7 +20,6 @@
 //           and all Cout columns (<= 256): wave w holds rows 32w..32w+31 as Cout/32 accumulator tiles.
 #include <math.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "hf_common.h"
 
@@ -549,12 +548,7 @@ static WgradPlan wgrad_plan(long long rows, int cout, int cin)
 static int resident_grid(int nt, long long ntiles)
 {
     static const int per_cu[9] = { 0, 5, 4, 3, 3, 2, 2, 2, 2 };
-    static int rounds = -1;
-    if (rounds < 0) {
-        const char *e = getenv("HF_GEMM_ROUNDS");
-        rounds = e ? atoi(e) : 2;
-        if (rounds < 1) rounds = 1;
-    }
+    static const int rounds = HF_DIAG_INT("HF_GEMM_ROUNDS", 2) < 1 ? 1 : HF_DIAG_INT("HF_GEMM_ROUNDS", 2);
     long long g = static_cast<long long>(kNumCU) * per_cu[nt < 1 ? 1 : (nt > 8 ? 8 : nt)] * rounds;
     if (g > kBnMaxBlocks) g = kBnMaxBlocks;
     if (g > ntiles) g = ntiles;

@@ -8,7 +8,6 @@
 // monotone, so there is one float T with  hit <=> s < T ; the host computes T exactly
 // (ball_threshold) and the kernels never take a square root.
 #include <math.h>
-#include <stdlib.h>
 
 #include <algorithm>
 
@@ -417,22 +416,29 @@ static int launch_ball_query_bruteforce(int b, int n, int m, float thresh, int n
     return launch_status();
 }
 
-// HF_BALL_QUERY=bruteforce forces the fallback kernel (used by the tests to cover both paths)
-static bool force_bruteforce()
-{
-    const char *e = getenv("HF_BALL_QUERY");
-    return e && e[0] == 'b';
-}
-
-static int launch_ball_query(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
-                             int center, int *idx, int *pts_cnt, float *grouped, hipStream_t st)
+// variant: HF_BQ_AUTO picks by shape; the others force one kernel (tests cover every path this way).
+//   auto: with a workspace and at least four rounds of the single-launch kernel's workgroups (the batched launches of a train
+//         step: 32 clouds of 4096 queries and up) -> the cell-sorted pair of kernels (ballquery_sorted.hip: the cell structure
+//         is built once per cloud; measured 52 us against 70 us at 80 clouds, equal at 32, 23 against 16 at 16 clouds);
+//         else the single-launch cell kernel (ballquery.hip); shapes outside both ranges (nsample > 128, n > 2^19 points per
+//         cloud, infinite radius) take the brute-force kernel.
+static int launch_ball_query(int variant, int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                             int center, int *idx, int *pts_cnt, float *grouped, void *workspace, size_t workspace_bytes,
+                             hipStream_t st)
 {
     const float thresh = ball_threshold(radius);
-    // main path: the cell kernel (ballquery.hip); shapes outside its range (nsample > 128, n > 2^19 points per cloud,
-    // infinite radius) take the brute-force kernel
-    if (!force_bruteforce()) {
-        const int rc = launch_ball_query_cell(b, n, m, radius, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
+    if (variant < HF_BQ_AUTO || variant > HF_BQ_SORTED) return HF_EINVAL;
+    if (variant == HF_BQ_SORTED)
+        return launch_ball_query_sorted(b, n, m, radius, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, workspace,
+                                        workspace_bytes, st);
+    if (variant == HF_BQ_AUTO && workspace && static_cast<long long>(b) * div_up(m, 128) >= 4LL * kNumCU) {
+        const int rc = launch_ball_query_sorted(b, n, m, radius, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, workspace,
+                                                workspace_bytes, st);
         if (rc != HF_EINVAL) return rc;
+    }
+    if (variant != HF_BQ_BRUTEFORCE) {
+        const int rc = launch_ball_query_cell(b, n, m, radius, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
+        if (rc != HF_EINVAL || variant == HF_BQ_CELL) return rc;
     }
     return launch_ball_query_bruteforce(b, n, m, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, st);
 }
@@ -656,7 +662,7 @@ HF_API int hf_query_ball_point(int b, int n, int m, float radius, int nsample, c
     // QueryBallPointGpuOp: radius > 0, nsample > 0 (tf_grouping.cpp:70-74); (b,n,3)/(b,m,3) (:79-85)
     if (!(radius > 0.0f) || nsample <= 0 || b < 0 || n <= 0 || m < 0 || !xyz1 || !xyz2 || !idx) return HF_EINVAL;
     if (b == 0 || m == 0) return HF_OK;
-    return launch_ball_query(b, n, m, radius, nsample, xyz1, xyz2, 0, idx, pts_cnt, nullptr, as_stream(stream));
+    return launch_ball_query(HF_BQ_AUTO, b, n, m, radius, nsample, xyz1, xyz2, 0, idx, pts_cnt, nullptr, nullptr, 0, as_stream(stream));
 }
 
 HF_API int hf_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1,
@@ -666,8 +672,20 @@ HF_API int hf_query_ball_group_xyz(int b, int n, int m, float radius, int nsampl
     if (!(radius > 0.0f) || nsample <= 0 || b < 0 || n <= 0 || m < 0 || !xyz1 || !xyz2 || !grouped_xyz)
         return HF_EINVAL;
     if (b == 0 || m == 0) return HF_OK;
-    return launch_ball_query(b, n, m, radius, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped_xyz,
+    return launch_ball_query(HF_BQ_AUTO, b, n, m, radius, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped_xyz, nullptr, 0,
                              as_stream(stream));
+}
+
+HF_API size_t hf_ball_query_workspace(int b, int n) { return ball_query_sorted_workspace(b, n); }
+
+HF_API int hf_query_ball_group_xyz_ws(int variant, int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                      const float *xyz2, int center, int *idx, int *pts_cnt, float *grouped_xyz,
+                                      void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (!(radius > 0.0f) || nsample <= 0 || b < 0 || n <= 0 || m < 0 || !xyz1 || !xyz2 || (!grouped_xyz && !idx)) return HF_EINVAL;
+    if (b == 0 || m == 0) return HF_OK;
+    return launch_ball_query(variant, b, n, m, radius, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped_xyz, workspace,
+                             workspace_bytes, as_stream(stream));
 }
 
 HF_API int hf_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,

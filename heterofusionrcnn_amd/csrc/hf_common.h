@@ -40,6 +40,27 @@ int launch_knn_grid(int b, int n, int m, int k, const float *data, const float *
 int launch_ball_query_cell(int b, int n, int m, float radius, float thresh, int nsample, const float *xyz1,
                            const float *xyz2, int center, int *idx, int *pts_cnt, float *grouped, hipStream_t st);
 
+// ballquery_sorted.hip: the cell-sorted pair of kernels (build once per cloud + query); HF_EINVAL = shape outside its range,
+// HF_EWORKSPACE = workspace missing / too small (ball_query_sorted_workspace(b, n) bytes, 16-byte aligned)
+size_t ball_query_sorted_workspace(int b, int n);
+int launch_ball_query_sorted(int b, int n, int m, float radius, float thresh, int nsample, const float *xyz1, const float *xyz2,
+                             int center, int *idx, int *pts_cnt, float *grouped, void *workspace, size_t workspace_bytes,
+                             hipStream_t st);
+
+// Diagnostic knobs (phase exits, forced tile shapes, ...) exist only in builds with -DHF_DIAG (scripts/probes/build_diag.sh);
+// the product library reads no environment variable on any launch path: HF_DIAG_INT(name, dflt) is the constant dflt.
+#ifdef HF_DIAG
+#include <stdlib.h>
+inline int hf_diag_env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && e[0] ? atoi(e) : dflt;
+}
+#define HF_DIAG_INT(name, dflt) hf_diag_env_int(name, dflt)
+#else
+#define HF_DIAG_INT(name, dflt) (dflt)
+#endif
+
 // status of the launch that was just enqueued (no synchronisation)
 inline int launch_status() { return hip_status(hipGetLastError()); }
 

@@ -15,7 +15,6 @@
 // The op is latency/VALU-bound on one CU per cloud (m-1 strictly sequential rounds), not
 // HBM-bound; DESIGN.md reports us/round.
 #include <math.h>
-#include <stdlib.h>
 
 #include "hf_common.h"
 
@@ -454,20 +453,6 @@ static int launch_fps_bucket(int b, int n, int m, const float *inp, int *out, hi
     return launch_status();
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e && e[0] ? atoi(e) : dflt;
-}
-
-// HF_FPS=plain|bucket overrides the size heuristic (tests cover both kernels this way)
-static int fps_mode()
-{
-    const char *e = getenv("HF_FPS");
-    if (!e || !e[0]) return 0;
-    return e[0] == 'p' ? 1 : (e[0] == 'b' ? 2 : 0);
-}
-
 template <int PPT, int NT>
 static int launch_fps_plain(int b, int n, int m, const float *inp, int *out, hipStream_t st)
 {
@@ -491,9 +476,10 @@ static int launch_fps_plain_nt(int b, int n, int m, const float *inp, int *out, 
     return HF_EINVAL;
 }
 
-static int launch_fps_onchip(int b, int n, int m, const float *inp, int *out, hipStream_t st)
+// mode: HF_FPS_AUTO by size, HF_FPS_PLAIN / HF_FPS_BUCKET forced (hf_farthest_point_sample_variant: the tests run both
+// kernels against the oracle); nt: workgroup size of the plain kernel (0 = by size)
+static int launch_fps_onchip(int b, int n, int m, const float *inp, int *out, hipStream_t st, int mode = HF_FPS_AUTO, int nt = 0)
 {
-    const int mode = fps_mode();
     // bucket pruning pays once there are enough rounds to amortise its prologue
     const bool bucket = mode == 2 || (mode == 0 && n >= 8192 && m >= 256);
     if (bucket) {
@@ -504,7 +490,6 @@ static int launch_fps_onchip(int b, int n, int m, const float *inp, int *out, hi
         if (ppt <= 8) return launch_fps_bucket<8>(b, n, m, inp, out, st);
         return launch_fps_bucket<16>(b, n, m, inp, out, st);
     }
-    int nt = env_int("HF_FPS_THREADS", 0);  // diagnostics: force the workgroup size of the plain kernel
     if (nt == 0) nt = n <= 4096 ? 256 : 512;  // fewer, fatter waves: measured faster at every size
     if (nt == 256 && n <= 256 * 16) return launch_fps_plain_nt<256>(b, n, m, inp, out, st);
     if (nt <= 512 && n <= 512 * 32) return launch_fps_plain_nt<512>(b, n, m, inp, out, st);
@@ -533,6 +518,19 @@ HF_API int hf_farthest_point_sample(int b, int n, int m, const float *inp, float
     if (!temp) return HF_EWORKSPACE;
     hipLaunchKernelGGL(fps_scratch_kernel, dim3(b), dim3(1024), 0, st, n, m, inp, temp, out);
     return launch_status();
+}
+
+HF_API int hf_farthest_point_sample_variant(int kernel, int threads, int b, int n, int m, const float *inp, float *temp, int *out,
+                                            hf_stream_t stream)
+{
+    if (b < 0 || n <= 0 || m <= 0 || !inp || !out) return HF_EINVAL;
+    if (kernel < HF_FPS_AUTO || kernel > HF_FPS_BUCKET || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
+        return HF_EINVAL;
+    if (b == 0) return HF_OK;
+    if (n > kFpsMaxPoints) return hf_farthest_point_sample(b, n, m, inp, temp, out, stream);
+    if (kernel == HF_FPS_PLAIN && threads != 0 && n > threads * (threads == 1024 ? 16 : 32)) return HF_EINVAL;
+    if (kernel == HF_FPS_PLAIN && threads == 256 && n > 256 * 16) return HF_EINVAL;
+    return launch_fps_onchip(b, n, m, inp, out, as_stream(stream), kernel, threads);
 }
 
 HF_API int hf_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out, hf_stream_t stream)

@@ -5,10 +5,25 @@ from . import _lib
 from ._lib import check, dev_tensor, ptr, require, stream_ptr
 
 
-def query_ball_point(radius, nsample, xyz1, xyz2):
+BALL_QUERY_VARIANTS = {"auto": 0, "cell": 1, "bruteforce": 2, "sorted": 3}   # HF_BQ_* of include/hfops.h
+
+
+def _ball_query(variant, b, n, m, radius, nsample, xyz1, xyz2, center, idx, cnt, grouped):
+    """hf_query_ball_group_xyz_ws with a workspace from the caching allocator (on the current stream)"""
+    L = _lib.lib()
+    v = BALL_QUERY_VARIANTS[variant]
+    ws, nbytes = None, 0
+    if v in (0, 3):
+        nbytes = L.hf_ball_query_workspace(b, n)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz1.device)
+    check(L.hf_query_ball_group_xyz_ws(v, b, n, m, radius, nsample, ptr(xyz1), ptr(xyz2), 1 if center else 0, ptr(idx), ptr(cnt),
+                                       ptr(grouped), ptr(ws), nbytes, stream_ptr()), "query_ball_point")
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2, variant="auto"):
     """xyz1 (B,N,3) data, xyz2 (B,M,3) queries -> idx (B,M,nsample) int32, pts_cnt (B,M) int32.
     Reference: tf_grouping.py:11-23; non-differentiable (:26).  Rows without any hit are zeros
-    (undefined in the reference, tf_grouping.cpp:88)."""
+    (undefined in the reference, tf_grouping.cpp:88).  variant forces one of the kernels (BALL_QUERY_VARIANTS): same output."""
     radius, nsample = float(radius), int(nsample)
     require(radius > 0, "QueryBallPoint expects positive radius")
     require(nsample > 0, "QueryBallPoint expects positive nsample")
@@ -21,8 +36,7 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     m = xyz2.shape[1]
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
-    check(_lib.lib().hf_query_ball_point(b, n, m, radius, nsample, ptr(xyz1), ptr(xyz2), ptr(idx), ptr(cnt),
-                                         stream_ptr()), "query_ball_point")
+    _ball_query(variant, b, n, m, radius, nsample, xyz1, xyz2, False, idx, cnt, None)
     return idx, cnt
 
 
@@ -142,7 +156,7 @@ def group_concat(points, idx, grouped_xyz, width=None, xyz_last=False):
     return _GroupConcat.apply(points, idx, grouped_xyz, width, bool(xyz_last))
 
 
-def query_ball_group(radius, nsample, xyz1, xyz2, center=True):
+def query_ball_group(radius, nsample, xyz1, xyz2, center=True, variant="auto"):
     """Fused query_ball_point + group_point(xyz1, idx) [- xyz2]: the op pair of
     pointnet_util.py:48-52 / 258-260 in one launch.  Returns (idx, pts_cnt, grouped_xyz);
     grouped_xyz carries the gradient of group_point w.r.t. xyz1 (and of the centring w.r.t. xyz2)
@@ -161,8 +175,7 @@ def query_ball_group(radius, nsample, xyz1, xyz2, center=True):
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     grouped = torch.empty((b, m, nsample, 3), dtype=torch.float32, device=xyz1.device)
-    check(_lib.lib().hf_query_ball_group_xyz(b, n, m, radius, nsample, ptr(xyz1), ptr(xyz2), 1 if center else 0,
-                                             ptr(idx), ptr(cnt), ptr(grouped), stream_ptr()), "query_ball_group")
+    _ball_query(variant, b, n, m, radius, nsample, xyz1, xyz2, center, idx, cnt, grouped)
     return idx, cnt, grouped
 
 

@@ -8,9 +8,13 @@ from . import _lib
 from ._lib import check, dev_tensor, ptr, require, stream_ptr
 
 
-def farthest_point_sample(npoint, inp):
+FPS_KERNELS = {"auto": 0, "plain": 1, "bucket": 2}   # HF_FPS_* of include/hfops.h
+
+
+def farthest_point_sample(npoint, inp, kernel="auto", threads=0):
     """inp (B,N,3) float32 -> (B,npoint) int32.  Reference: tf_sampling.py:61-69 (note the
-    Python argument order (npoint, xyz)); non-differentiable (ops.NoGradient, :72)."""
+    Python argument order (npoint, xyz)); non-differentiable (ops.NoGradient, :72).
+    kernel / threads force one of the on-chip kernels (FPS_KERNELS; the tests compare them): same output."""
     npoint = int(npoint)
     require(npoint > 0, "FarthestPointSample expects positive npoint")
     require(inp.dim() == 3 and inp.shape[2] == 3, "FarthestPointSample expects (batch_size,num_points,3) inp shape")
@@ -21,6 +25,10 @@ def farthest_point_sample(npoint, inp):
     L = _lib.lib()
     ws = L.hf_fps_workspace(b, n)
     temp = torch.empty((ws // 4,), dtype=torch.float32, device=inp.device) if ws else None
+    if kernel != "auto" or threads:
+        check(L.hf_farthest_point_sample_variant(FPS_KERNELS[kernel], int(threads), b, n, npoint, ptr(inp), ptr(temp), ptr(out),
+                                                 stream_ptr()), "farthest_point_sample")
+        return out
     check(L.hf_farthest_point_sample(b, n, npoint, ptr(inp), ptr(temp), ptr(out), stream_ptr()), "farthest_point_sample")
     return out
 

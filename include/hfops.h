@@ -56,6 +56,14 @@ int hf_last_hip_error(void); /* hipError_t of the last HF_EHIP on this thread */
  * distances on chip when n <= hf_fps_onchip_limit() and then ignores it (may be NULL);
  * above that limit it needs hf_fps_workspace(b,n) bytes there. */
 int hf_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, hf_stream_t stream);
+/* The same op with the kernel forced (the tests run every kernel against the oracle): HF_FPS_PLAIN = points and running
+ * distances in registers, `threads` = 256 / 512 / 1024 per cloud (0: by size); HF_FPS_BUCKET = the spatially bucketed kernel
+ * with exact pruning; HF_FPS_AUTO = what hf_farthest_point_sample picks.  Identical output whatever the choice. */
+#define HF_FPS_AUTO 0
+#define HF_FPS_PLAIN 1
+#define HF_FPS_BUCKET 2
+int hf_farthest_point_sample_variant(int kernel, int threads, int b, int n, int m, const float *inp, float *temp, int *out,
+                                     hf_stream_t stream);
 size_t hf_fps_workspace(int b, int n);
 int hf_fps_onchip_limit(void);
 
@@ -90,6 +98,21 @@ int hf_group_point_grad(int b, int n, int c, int m, int nsample, const float *gr
  * (`center` != 0: pointnet_util.py:50-52, same fp32 subtraction).  idx / pts_cnt may be NULL. */
 int hf_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
                             int center, int *idx, int *pts_cnt, float *grouped_xyz, hf_stream_t stream);
+
+/* The same op pair with a caller-owned workspace (hf_ball_query_workspace(b, n) bytes, 16-byte aligned) and an explicit
+ * kernel choice.  With a workspace the batched shapes of a train step (more workgroups than one round of the single-launch
+ * kernel) build the cell structure of every cloud ONCE (counting sort by hashed cell) and answer all query tiles from it.
+ * variant: HF_BQ_AUTO by shape, or one kernel forced (HF_BQ_CELL single launch, HF_BQ_BRUTEFORCE, HF_BQ_SORTED) -- the tests
+ * run every kernel against the oracle this way.  grouped_xyz may be NULL (query_ball_point alone); outputs identical to
+ * hf_query_ball_point / hf_query_ball_group_xyz whatever the variant. */
+#define HF_BQ_AUTO 0
+#define HF_BQ_CELL 1
+#define HF_BQ_BRUTEFORCE 2
+#define HF_BQ_SORTED 3
+size_t hf_ball_query_workspace(int b, int n);
+int hf_query_ball_group_xyz_ws(int variant, int b, int n, int m, float radius, int nsample, const float *xyz1,
+                               const float *xyz2, int center, int *idx, int *pts_cnt, float *grouped_xyz, void *workspace,
+                               size_t workspace_bytes, hf_stream_t stream);
 
 /* replaces selectionSortLauncher(b,n,m,k,dist,outi,out)  grouping/tf_grouping.cpp:108 (kernel :83-123) */
 int hf_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, float *out, hf_stream_t stream);

@@ -1,0 +1,53 @@
+"""ball query: the single-launch cell kernel against the cell-sorted pair (build + query) at the headline shape (8 clouds)
+and at the batched shapes of the train step; bursts of launches through the C ABI, HIP events on the launch stream"""
+import json, sys, os
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+import heterofusionrcnn_amd as hf
+from heterofusionrcnn_amd import _lib
+L = _lib.lib()
+out = {}
+shapes = ((8, 16384, 4096, 0.5, 32), (80, 16384, 4096, 0.5, 32), (80, 16384, 4096, 0.1, 16), (80, 4096, 1024, 1.0, 32),
+          (16, 16384, 4096, 0.5, 32), (32, 16384, 4096, 0.5, 32), (1, 16384, 4096, 0.5, 32), (80, 1024, 256, 2.0, 32))
+if os.environ.get("BQ_SHAPES"):
+    shapes = tuple(shapes[int(i)] for i in os.environ["BQ_SHAPES"].split(","))
+for (clouds, n, m, r, k) in shapes:
+    xyz = torch.from_numpy(bench.kitti_uniform(np.random.default_rng(2000), clouds, n)).cuda()
+    new_xyz = hf.gather_point(xyz, hf.farthest_point_sample(m, xyz))
+    idx = torch.empty((clouds, m, k), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((clouds, m), dtype=torch.int32, device="cuda")
+    grouped = torch.empty((clouds, m, k, 3), dtype=torch.float32, device="cuda")
+    nbytes = L.hf_ball_query_workspace(clouds, n)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    ref = None
+    for name, v in (("cell", 1), ("sorted", 3), ("auto", 0)):
+        args = (v, clouds, n, m, r, k, xyz.data_ptr(), new_xyz.data_ptr(), 1, idx.data_ptr(), cnt.data_ptr(), grouped.data_ptr(),
+                ws.data_ptr(), nbytes, st)
+        idx.zero_(); grouped.zero_()
+        for _ in range(5):
+            assert L.hf_query_ball_group_xyz_ws(*args) == 0
+        torch.cuda.synchronize()
+        if os.environ.get("HF_BQ_STOP"):
+            pass                                   # phase exits: outputs are invalid by design
+        elif ref is None:
+            ref = (idx.clone(), cnt.clone(), grouped.clone())
+        else:
+            assert torch.equal(idx, ref[0]) and torch.equal(cnt, ref[1]) and torch.equal(grouped, ref[2]), name
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        launches = 100
+        e0.record()
+        for _ in range(launches):
+            L.hf_query_ball_group_xyz_ws(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / launches
+        alg = (4 * 3 * clouds * (n + m) + 4 * clouds * m * (k + 1)) + (4 * 3 * clouds * n + 4 * clouds * m * k + 4 * clouds * m * k * 3)
+        res[name] = {"us": round(us, 2), "us_per_cloud": round(us / clouds, 3), "frac_two_op_bytes": round(alg / (us * 1e-6) / 8e12, 4)}
+    out["%dx%dx%d r%.1f k%d" % (clouds, n, m, r, k)] = res
+    print(clouds, n, m, r, k, res, flush=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r3", "bq_sorted_timing%s.json" % os.environ.get("HF_BQ_G", "")), "w"), indent=1)

@@ -99,3 +99,33 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     # empty problems are OK and launch nothing
     assert L.hf_query_ball_point(0, 4, 2, 0.1, 4, one, one, one, one, None) == _lib.HF_OK
     assert L.hf_group_point(0, 4, 3, 2, 2, one, one, one, None) == _lib.HF_OK
+
+
+def test_product_library_reads_no_environment_variable():
+    """the diagnostic knobs of the kernels (phase exits that leave outputs unwritten, forced tile shapes, kernel overrides) exist
+    only in -DHF_DIAG builds: the shipped library neither imports getenv nor carries their names"""
+    import subprocess
+    from heterofusionrcnn_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"HF_QBP_", b"HF_BEV_STOP", b"HF_NMS_STOP", b"HF_GEMM_ROUNDS", b"HF_BALL_QUERY", b"HF_FPS"):
+        assert name not in blob, name
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+
+
+def test_ball_query_variant_and_workspace_argument_checks():
+    from heterofusionrcnn_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(16)
+    assert L.hf_ball_query_workspace(0, 100) == 0
+    # per cloud: 16 bytes per point + the bucket table (1024 / 4096 / 16384 buckets + 4 words), 16-byte multiples
+    assert L.hf_ball_query_workspace(2, 1000) == 2 * (16 * 1000 + 4 * (1024 + 4))
+    assert L.hf_ball_query_workspace(8, 16384) == 8 * (16 * 16384 + 4 * (16384 + 4))
+    args = (1, 64, 8, 0.5, 4, one, one, 1, one, one, one)
+    assert L.hf_query_ball_group_xyz_ws(7, *args, None, 0, None) == _lib.HF_EINVAL                # unknown variant
+    assert L.hf_query_ball_group_xyz_ws(3, *args, None, 0, None) == _lib.HF_EWORKSPACE            # sorted needs a workspace
+    assert L.hf_query_ball_group_xyz_ws(3, *args, one, 16, None) == _lib.HF_EWORKSPACE            # ... of the right size
+    assert L.hf_query_ball_group_xyz_ws(0, 1, 64, 8, -1.0, 4, one, one, 1, one, one, one, None, 0, None) == _lib.HF_EINVAL
+    assert L.hf_farthest_point_sample_variant(5, 0, 1, 64, 8, one, None, one, None) == _lib.HF_EINVAL
+    assert L.hf_farthest_point_sample_variant(1, 300, 1, 64, 8, one, None, one, None) == _lib.HF_EINVAL
+    assert L.hf_farthest_point_sample_variant(1, 256, 1, 8000, 8, one, None, one, None) == _lib.HF_EINVAL

@@ -288,6 +288,9 @@ def test_full_width_xconv_level_equals_op_by_op_form():
     ref_grads = torch.autograd.grad(ref, [fts] + params, go)
     torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3)
     names = ["fts"] + [nm for nm, _ in m.named_parameters()]
+    # a few gradients are analytically zero (x1's BatchNorm shift is removed again by x2's mean subtraction): both routes
+    # return rounding noise there, so the floor of the bound is a fraction of the LARGEST parameter gradient
+    gmax = max(float(r.abs().max()) for r in ref_grads[1:])
     for nm, a, r in zip(names, grads, ref_grads):
         scale = float(r.abs().max()) + 1e-6
-        assert float((a - r).abs().max()) <= 5e-3 * scale + 1e-5, (nm, float((a - r).abs().max()), scale)
+        assert float((a - r).abs().max()) <= 5e-3 * scale + 1e-4 * gmax, (nm, float((a - r).abs().max()), scale, gmax)

@@ -72,14 +72,10 @@ def test_golden_grouping(hf):
 
 
 def _fps_both_kernels(hf, m, xyz_dev):
-    """run the plain and the bucketed FPS kernel (HF_FPS override) and insist they agree"""
+    """run the plain and the bucketed FPS kernel (hf_farthest_point_sample_variant) and insist they agree"""
     outs = []
     for mode in ("plain", "bucket"):
-        os.environ["HF_FPS"] = mode
-        try:
-            outs.append(hf.farthest_point_sample(m, xyz_dev))
-        finally:
-            os.environ.pop("HF_FPS", None)
+        outs.append(hf.farthest_point_sample(m, xyz_dev, kernel=mode))
     assert torch.equal(outs[0], outs[1]), "plain and bucketed FPS disagree"
     auto = hf.farthest_point_sample(m, xyz_dev)
     assert torch.equal(auto, outs[0])
@@ -189,7 +185,8 @@ def test_ball_query_both_kernels_and_stress_paths(hf, oracle_mod):
     """cell kernel (ballquery.hip): clustered queries, dense data (candidate buffer overflow -> chunked walk with early
     stop, more than two hits per list -> serial hand-off), hits >> nsample, several register segments (n > 16384), every
     LDS geometry (nsample 32/64/128), the exhaustive mode (coordinates ~1e6 radii from the origin) and the brute-force
-    kernel (nsample > 128, n > 2^19, HF_BALL_QUERY=bruteforce) -- all must give the oracle's rows"""
+    kernel (nsample > 128, n > 2^19, variant="bruteforce"), and the cell-sorted pair of kernels (variant="sorted": dense buckets ->
+    more than two hits per lane, the exhaustive walk, every table size) -- all must give the oracle's rows"""
     rng = np.random.default_rng(77)
     cases = []
     # clustered queries: ~2900 of 3000 queries sit in a 1 cm cube -> one slab owns them all (rounds)
@@ -222,17 +219,16 @@ def test_ball_query_both_kernels_and_stress_paths(hf, oracle_mod):
     # more than 2^19 points per cloud: outside the cell kernel's index packing -> brute force
     x1 = kitti_uniform(rng, 1, (1 << 19) + 5)
     cases.append((x1, x1[:, -12:].copy(), 0.3, 16))
-    for mode in ("", "bruteforce"):
-        os.environ["HF_BALL_QUERY"] = mode
-        try:
-            for (a, b, r, ns) in cases:
-                oi, oc = oracle_mod.query_ball_point(r, ns, a, b)
-                idx, cnt, gx = hf.query_ball_group(r, ns, dev(a), dev(b), center=False)
-                assert np.array_equal(host(idx), oi), (mode, r, ns)
-                assert np.array_equal(host(cnt), oc), (mode, r, ns)
-                assert np.array_equal(host(gx), oracle_mod.group_point(a, oi)), (mode, r, ns)
-        finally:
-            os.environ.pop("HF_BALL_QUERY", None)
+    for (a, b, r, ns) in cases:
+        oi, oc = oracle_mod.query_ball_point(r, ns, a, b)
+        for mode in ("auto", "bruteforce") + (("sorted",) if ns <= 128 else ()):
+            idx, cnt, gx = hf.query_ball_group(r, ns, dev(a), dev(b), center=False, variant=mode)
+            assert np.array_equal(host(idx), oi), (mode, r, ns)
+            assert np.array_equal(host(cnt), oc), (mode, r, ns)
+            assert np.array_equal(host(gx), oracle_mod.group_point(a, oi)), (mode, r, ns)
+        if ns <= 128:
+            i2, c2 = hf.query_ball_point(r, ns, dev(a), dev(b), variant="sorted")
+            assert np.array_equal(host(i2), oi) and np.array_equal(host(c2), oc), ("sorted, no grouping", r, ns)
 
 
 def test_ball_threshold_boundary(hf, oracle_mod):
@@ -1412,24 +1408,16 @@ def test_fuzz_all_ops_against_oracle(hf, oracle_mod):
         r = float(rng.choice([0.02, 0.1, 0.5, 2.0])) * scale / 4
         ns = int(rng.choice([1, 3, 16, 32, 64, 100, 140]))
         oi, oc = oracle_mod.query_ball_point(r, ns, x1, x2)
-        for mode in ("", "bruteforce"):
-            os.environ["HF_BALL_QUERY"] = mode
-            try:
-                idx, cnt, gx = hf.query_ball_group(r, ns, dev(x1), dev(x2), center=True)
-            finally:
-                os.environ.pop("HF_BALL_QUERY", None)
+        for mode in ("auto", "bruteforce") + (("sorted", "cell") if ns <= 128 else ()):
+            idx, cnt, gx = hf.query_ball_group(r, ns, dev(x1), dev(x2), center=True, variant=mode)
             assert np.array_equal(host(idx), oi) and np.array_equal(host(cnt), oc), (trial, mode, b, n, m, r, ns)
             assert np.array_equal(host(gx), oracle_mod.group_point(x1, oi) - x2[:, :, None, :]), (trial, mode)
         # FPS on every kernel
         mm = int(min(n + 3, rng.choice([1, 2, 17, 128, 700])))
         want = oracle_mod.farthest_point_sample(mm, x1)
-        variants = [("plain", "1024"), ("plain", "512"), ("bucket", "0")] + ([("plain", "256")] if n <= 4096 else [])
+        variants = [("plain", 1024), ("plain", 512), ("bucket", 0)] + ([("plain", 256)] if n <= 4096 else [])
         for mode, nt in variants:
-            os.environ["HF_FPS"], os.environ["HF_FPS_THREADS"] = mode, nt
-            try:
-                got = hf.farthest_point_sample(mm, dev(x1))
-            finally:
-                os.environ.pop("HF_FPS", None); os.environ.pop("HF_FPS_THREADS", None)
+            got = hf.farthest_point_sample(mm, dev(x1), kernel=mode, threads=nt)
             assert np.array_equal(host(got), want), (trial, mode, nt, b, n, mm)
         # three_nn / kNN (x1 as known / data, x2 as unknown / queries)
         d3, i3 = hf.three_nn(dev(x2), dev(x1))
