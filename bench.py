@@ -329,31 +329,34 @@ def per_op_table(hf, xyz):
               torch.rand(B, N0, kcls, 3, device="cuda") + 1]
     t["bin_box_decode_16384x3_us"] = time_op(lambda: box_codec.decode(xyz, 0, *dec_in, [3.0] * kcls, [0.5] * kcls,
                                                                      0.25 * np.pi, 0.5 * np.pi / 12))
-    # two-stage inference flow of BASELINE config 5 (RPN -> NMS -> crop -> RCNN -> NMS), random weights
+    # two-stage inference of BASELINE config 5 at its own sizes (RPN of rpn_multiclass.config with image fusion -> 9000 boxes ->
+    # NMS 0.8 -> 100 proposals -> 512-point crops of 288 channels -> the RCNN of rcnn_multiclass.config -> NMS 0.01), random
+    # weights, 8 frames per batch; frames filtered to the camera's field of view
     from heterofusionrcnn_amd.two_stage import TwoStageDetector
     torch.manual_seed(0)
     det = TwoStageDetector().cuda().eval()
-    us = time_op(lambda: det(xyz, intensity_for_infer(xyz)), iters=3, warm=1)
+    fx = torch.from_numpy(kitti_frustum(np.random.default_rng(7), B, N0)).cuda()
+    inten0 = torch.from_numpy(np.random.default_rng(8).uniform(-0.5, 0.5, (B, N0, 1)).astype(np.float32)).cuda()
+    img = torch.randn(B, IMG_H, IMG_W, IMG_C, device="cuda")
+    cal = torch.from_numpy(KITTI_P2).cuda().repeat(B, 1, 1).contiguous()
+    us = time_op(lambda: det(fx, inten0, img, cal), iters=3, warm=1)
     t["two_stage_infer_ms_per_batch8"] = us / 1e3
     t["two_stage_infer_frames_per_s"] = B / (us * 1e-6)
+    t["two_stage_rpn_stage_ms"] = time_op(lambda: det.rpn_stage(fx, inten0, img, cal), iters=3, warm=1) / 1e3
     # the same flow with the RPN geometry of the next batches computed ahead on side streams (two_stage.run_sharded)
     from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
-    pf = GeometryPrefetcher(det.rpn.geometry, depth=2)
-    inten0 = intensity_for_infer(xyz)
-    pf.submit(xyz); pf.submit(xyz)
+    pf = GeometryPrefetcher(det.geometry, depth=2)
+    pf.submit(fx); pf.submit(fx)
 
     def piped():
         geo = pf.get()
-        pf.submit(xyz)
-        det(xyz, inten0, geometry=geo)
+        pf.submit(fx)
+        det(fx, inten0, img, cal, geometry=geo)
     us = time_op(piped, iters=6, warm=2)
     t["two_stage_infer_pipelined_ms_per_batch8"] = us / 1e3
     t["two_stage_infer_pipelined_frames_per_s"] = B / (us * 1e-6)
+    t["two_stage_config"] = "rpn_multiclass.config + rcnn_multiclass.config at their own sizes (pre-NMS 9000, 100 RoIs/frame, R=512, C=288), random weights"
     return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in t.items()}
-
-
-def intensity_for_infer(xyz):
-    return torch.zeros(xyz.shape[0], xyz.shape[1], 1, device=xyz.device)
 
 
 def _cpu_chain(frames, seed, levels, fp_channels):

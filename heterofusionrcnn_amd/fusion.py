@@ -114,3 +114,56 @@ def fuse_point_image_features(pc_fts, proj_img_fts, method="concat", div=2.0, ma
     if masks is not None:
         pc_fts, proj_img_fts = pc_fts * masks[0], proj_img_fts * masks[1]
     return torch.cat([pc_fts, proj_img_fts], dim=-1)
+
+
+def project_boxes_to_image(boxes_3d, calib, image_hw):
+    """hf/core/projection.py:35-96 (tf_project_to_image_space) for every frame at once: boxes_3d (B,n,7) [x,y,z,l,w,h,ry]
+    (y = bottom), calib (B,3,4), image_hw = (h, w) -> (corners (B,n,4) [x1,y1,x2,y2] in pixels, the same normalised by
+    [w,h,w,h]): the 8 corners of a box are projected and the 2-D box is their bounding rectangle."""
+    from .modules import box_3d_to_box_8co
+    b, n, _ = boxes_3d.shape
+    corners = box_3d_to_box_8co(boxes_3d.reshape(-1, 7)).transpose(1, 2).reshape(b, n * 8, 3)    # (B, n*8, 3)
+    hom = torch.cat([corners, torch.ones_like(corners[..., :1])], dim=-1)
+    pix = torch.einsum("bij,bnj->bni", calib, hom)
+    pix = (pix / pix[..., 2:3])[..., :2].reshape(b, n, 8, 2)
+    lo, hi = pix.min(dim=2).values, pix.max(dim=2).values
+    box = torch.cat([lo, hi], dim=-1)
+    h, w = image_hw
+    return box, box / torch.tensor([w, h, w, h], dtype=box.dtype, device=box.device)
+
+
+def crop_and_resize(img_fts, boxes_norm_yxyx, box_ind, crop_size, extrapolation_value=0.0):
+    """tf.image.crop_and_resize (bilinear) as the RCNN uses it on the image feature map (rcnn_model.py:494-500): img_fts
+    (B,H,W,C), boxes (N,4) [y1,x1,y2,x2] normalised, box_ind (N) -> (N,crop,crop,C).  Sample i of a crop sits at
+    y1 (H-1) + i (y2-y1)(H-1)/(crop-1); a sample outside [0, H-1] x [0, W-1] takes the extrapolation value.
+    Plain torch gathers (N * crop^2 * 4 rows of C floats); TensorFlow is not importable here: parity unpinned beyond the
+    documented formula (tests/test_rcnn.py checks it against a loop)."""
+    b, h, w, c = img_fts.shape
+    n = boxes_norm_yxyx.shape[0]
+    ch = cw = int(crop_size)
+    y1, x1, y2, x2 = boxes_norm_yxyx.unbind(-1)
+    steps_y = torch.arange(ch, device=img_fts.device, dtype=img_fts.dtype)
+    steps_x = torch.arange(cw, device=img_fts.device, dtype=img_fts.dtype)
+    if ch > 1:
+        ys = y1[:, None] * (h - 1) + steps_y[None] * ((y2 - y1)[:, None] * (h - 1) / (ch - 1))
+    else:
+        ys = (0.5 * (y1 + y2) * (h - 1))[:, None]
+    if cw > 1:
+        xs = x1[:, None] * (w - 1) + steps_x[None] * ((x2 - x1)[:, None] * (w - 1) / (cw - 1))
+    else:
+        xs = (0.5 * (x1 + x2) * (w - 1))[:, None]
+    oky = (ys >= 0) & (ys <= h - 1)
+    okx = (xs >= 0) & (xs <= w - 1)
+    y0f, x0f = torch.floor(ys), torch.floor(xs)
+    ly, lx = (ys - y0f)[:, :, None, None], (xs - x0f)[:, None, :, None]
+    y0 = y0f.long().clamp(0, h - 1)
+    yb = torch.ceil(ys).long().clamp(0, h - 1)
+    x0 = x0f.long().clamp(0, w - 1)
+    xb = torch.ceil(xs).long().clamp(0, w - 1)
+    bi = box_ind.long()[:, None, None]
+    g = lambda yy, xx: img_fts[bi, yy[:, :, None], xx[:, None, :]]             # (N, ch, cw, C)
+    top = g(y0, x0) + (g(y0, xb) - g(y0, x0)) * lx
+    bot = g(yb, x0) + (g(yb, xb) - g(yb, x0)) * lx
+    out = top + (bot - top) * ly
+    ok = (oky[:, :, None] & okx[:, None, :])[..., None]
+    return torch.where(ok, out, torch.full_like(out, extrapolation_value))

@@ -300,6 +300,8 @@ class PointCnnBackbone(nn.Module):
             self.dec.append(XConv(k, d, fts_c, c, c_prev // 4, 1, cfg.with_x, False))                     # :326-348
             self.fuse.append(Dense(c + chans[qi + 1], c))                                                # :349-352
             c_last = c
+        if not cfg.xdconv:
+            c_last = chans[-1]
         self.fc = nn.ModuleList()
         self.fc_drop = []
         for (w, rate) in cfg.fc:
@@ -333,7 +335,7 @@ class PointCnnBackbone(nn.Module):
             src = fts[pi + 1] if li == 0 else cur
             x = self.dec[li](pts[pi + 1], src, pts[qi + 1], g["dec"][li])
             cur = self.fuse[li](torch.cat([x, fts[qi + 1]], dim=-1))
-        out = cur
+        out = cur if cur is not None else fts[-1]        # no decoder (the RCNN's extractor): the last encoder layer
         for layer, rate in zip(self.fc, self.fc_drop):
             out = F.dropout(layer(out), p=rate, training=self.training)                                   # :371-384
         return out

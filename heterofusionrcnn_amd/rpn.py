@@ -273,7 +273,7 @@ class RpnHeads(nn.Module):
         self.fc = nn.ModuleList(layers)
         self.out = DenseEluBN(c, cfg.head_width * k, activation=False)
 
-    def forward(self, pc_fts, proj_img_fts=None):
+    def forward(self, pc_fts, proj_img_fts=None, return_fused=False):
         b, p, c = pc_fts.shape
         seg_logits = linear_narrow(pc_fts, self.seg.weight, self.seg.bias)   # (B,P,K+1)
         x = pc_fts
@@ -283,10 +283,11 @@ class RpnHeads(nn.Module):
                 masks = path_drop_masks(self.cfg.path_drop[0], self.cfg.path_drop[1], torch.rand(3, device=pc_fts.device))
             x = fuse_point_image_features(pc_fts, proj_img_fts, self.cfg.fusion, masks=masks)
         x = x.reshape(b * p, -1)
+        fused = x
         for layer, rate in zip(self.fc, self.drop):
             x = F.dropout(layer(x), p=rate, training=self.training)     # tf.layers.dropout(rate)
         out = self.out(x).reshape(b, p, self.cfg.num_classes, self.cfg.head_width)
-        return seg_logits, out
+        return (seg_logits, out, fused.reshape(b, p, -1)) if return_fused else (seg_logits, out)
 
 
 def parse_rpn_output(out, nbx, nbz, nbt):
@@ -395,6 +396,33 @@ class RpnModel(nn.Module):
         if self.cfg.fusion != "none":
             proj = project_gather(xyz, calib, img_fts)
         return self.heads(pc_fts, proj)
+
+    @torch.no_grad()
+    def propose(self, xyz, intensity, geometry=None, img_fts=None, calib=None, pre_nms_size=9000, nms_thresh=0.8, post_nms_size=100):
+        """The RPN in test mode (rpn_model.py:455-476, 593-700, 845-866): segmentation softmax -> per-point score (the best
+        foreground class) and class, the bin-based head decoded around every point for its predicted class, the
+        pre_nms_size best points, oriented BEV NMS, post_nms_size proposals per frame (fixed_num_proposal_nms: the keep
+        list is padded with its first entry, bev_iou.cpp:110-112).  Also returns what the reference saves for the second
+        stage: the fused per-point features, the foreground mask and the point scores."""
+        from .bev_iou import oriented_nms_batched
+        from .modules import boxes3d_to_bev
+        cfg = self.cfg
+        pc_fts = self.backbone(xyz, intensity, geometry)
+        proj = project_gather(xyz, calib, img_fts) if cfg.fusion != "none" else None
+        seg_logits, head, fused = self.heads(pc_fts, proj, return_fused=True)
+        prob = torch.softmax(seg_logits, dim=-1)
+        scores, fg_cls = prob[..., 1:].max(dim=-1)                              # seg_scores, seg_fg_preds
+        fg_mask = prob.argmax(dim=-1) > 0                                       # seg_preds > 0 (test mode, :505-507)
+        boxes = box_codec.decode_head(head, xyz, 0, cfg.cluster_sizes, cfg.num_bin_xz, cfg.num_bin_xz, cfg.theta_bin_num,
+                                      cfg.xz_search_range, cfg.xz_bin_len, cfg.r_theta, cfg.delta_theta, cls=fg_cls)
+        k = min(pre_nms_size, xyz.shape[1])
+        top_s, top_i = torch.topk(scores, k, dim=1)                             # tf.nn.top_k(sorted=True), :647-655
+        top_b = torch.gather(boxes, 1, top_i.unsqueeze(-1).expand(-1, -1, 7))
+        keep, num = oriented_nms_batched(boxes3d_to_bev(top_b).contiguous(), nms_thresh)
+        ind = keep[:, :post_nms_size].long()
+        return {"proposals": torch.gather(top_b, 1, ind.unsqueeze(-1).expand(-1, -1, 7)), "proposal_scores": torch.gather(top_s, 1, ind),
+                "num_before_padding": torch.clamp(num, max=post_nms_size), "rpn_fts": fused, "fg_mask": fg_mask, "point_scores": scores,
+                "pre_nms_boxes": top_b, "pre_nms_scores": top_s, "keep": keep, "num_kept": num}
 
     def loss(self, xyz, seg_logits, head, label_cls, label_reg):
         with torch.no_grad():

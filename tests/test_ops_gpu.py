@@ -1099,52 +1099,6 @@ def test_sample_and_group_knn_mode(hf, oracle_mod):
     assert (host(idx)[:, :, 0] == oracle_mod.farthest_point_sample(128, xyz)).all()  # nearest neighbour = itself
 
 
-def test_two_stage_inference_flow(hf, oracle_mod):
-    """RPN -> top-k -> oriented NMS -> expand -> crop -> canonical transform -> RCNN -> NMS on 2 frames;
-    checks the hand-offs between the ops against the oracle (crop) and against their definitions"""
-    from heterofusionrcnn_amd import dp, modules
-    from heterofusionrcnn_amd.two_stage import TwoStageDetector, canonical_transform, expand_proposals, run_sharded
-    torch.manual_seed(3)
-    rng = np.random.default_rng(3)
-    det = TwoStageDetector(pre_nms_size=2048, rpn_nms_size=24, roi_crop_size=128).cuda().eval()
-    xyz = dev(kitti_uniform(rng, 2, 16384))
-    inten = dev(rng.uniform(-.5, .5, (2, 16384, 1)).astype(np.float32))
-    feats, proposals, pscores, point_scores = det.rpn_stage(xyz, inten)
-    assert proposals.shape == (2, 24, 7) and torch.isfinite(proposals).all()
-    # proposals of a frame do not suppress each other at the RPN threshold
-    for b in range(2):
-        uniq = torch.unique(proposals[b], dim=0)
-        _, iou = hf.compute_bev_iou(modules.boxes3d_to_bev(uniq), modules.boxes3d_to_bev(uniq))
-        iou.fill_diagonal_(0)
-        assert (iou <= 0.8 + TOL).all()
-    # the crop hand-off equals the oracle's crop of the same expanded boxes
-    flat = proposals.reshape(-1, 7)
-    boxes8 = modules.box_3d_to_box_8co(expand_proposals(flat, 1.0)).contiguous()
-    box_ind = torch.arange(2, device="cuda", dtype=torch.int32).repeat_interleave(24)
-    fg = point_scores > 0.5
-    got = hf.pc_crop_and_sample(xyz, feats.contiguous(), inten, fg, boxes8, box_ind, 128)
-    want = oracle_mod.pc_crop_and_sample(host(xyz), host(feats), host(inten), host(fg), host(boxes8), host(box_ind), 128)
-    for g, w in zip(got, want):
-        assert np.array_equal(host(g), w)
-    # canonical transform: the box centre maps to the origin, distances are preserved
-    ct = canonical_transform(got[0], flat)
-    np.testing.assert_allclose(host(torch.norm(ct, dim=2)), host(torch.norm(got[0] - flat[:, None, :3], dim=2)), atol=1e-4)
-    dets = det(xyz, inten)
-    assert len(dets) == 2 and all(d["boxes"].shape[1] == 7 and len(d["boxes"]) == len(d["scores"]) <= 24 for d in dets)
-    ctx = dp.DPContext(0, 1, 0, torch.device("cuda", 0))
-    merged = run_sharded(det, [xyz[0], xyz[1]], [inten[0], inten[1]], ctx, frames_per_batch=2)
-    assert sorted(merged) == [0, 1] and torch.equal(merged[0]["boxes"], dets[0]["boxes"].cpu())
-    # more batches than prefetch slots (geometry of batch i+2 submitted while batch i runs): same detections as
-    # the unpipelined model, frame by frame
-    frames = [xyz[0], xyz[1], xyz[1], xyz[0], xyz[1]]
-    intens = [inten[0], inten[1], inten[1], inten[0], inten[1]]
-    piped = run_sharded(det, frames, intens, ctx, frames_per_batch=1)
-    assert sorted(piped) == [0, 1, 2, 3, 4]
-    for j, (f, it) in enumerate(zip(frames, intens)):
-        alone = det(f[None], it[None])[0]
-        assert torch.equal(piped[j]["boxes"], alone["boxes"].cpu()) and torch.equal(piped[j]["scores"], alone["scores"].cpu())
-
-
 def test_caller_side_ops_on_empty_and_ragged_shapes(hf, oracle_mod):
     """zero-size and non-tile-multiple shapes through the entry points added for the SA/FP callers"""
     from heterofusionrcnn_amd import modules
@@ -1335,33 +1289,6 @@ def test_mlp_entry_points_reject_bad_arguments(hf):
     with pytest.raises(RuntimeError):
         modules.SharedMLPLayer(3, 4)(torch.randn(8, 3))
     assert L.hf_linear_wgrad_workspace(0, 4, 4) == 0
-
-
-def test_two_stage_with_image_fusion_branch(hf):
-    """the optional image branch: features under the projected points are concatenated to the point features for the
-    RPN head and for the RCNN crop; points that project outside the image contribute zeros"""
-    from heterofusionrcnn_amd.fusion import fuse_point_image_features, project_gather
-    from heterofusionrcnn_amd.two_stage import TwoStageDetector
-    torch.manual_seed(5)
-    rng = np.random.default_rng(5)
-    det = TwoStageDetector(pre_nms_size=1024, rpn_nms_size=16, roi_crop_size=64, img_channels=8).cuda().eval()
-    xyz = dev(kitti_uniform(rng, 2, 16384))
-    inten = dev(rng.uniform(-.5, .5, (2, 16384, 1)).astype(np.float32))
-    img = dev(rng.standard_normal((2, 48, 160, 8)).astype(np.float32))
-    calib = dev(np.tile(np.array([[90.0, 0, 80, 5], [0, 90.0, 24, 0], [0, 0, 1, 0.003]], np.float32), (2, 1, 1)))
-    feats, proposals, _, scores = det.rpn_stage(xyz, inten, None, img, calib)
-    assert feats.shape == (2, 16384, 128 + 8) and proposals.shape == (2, 16, 7)
-    proj, pix = project_gather(xyz, calib, img, return_pixels=True)
-    assert torch.equal(feats[..., 128:], proj)
-    outside = (pix[..., 0] < 0) | (pix[..., 0] >= 160) | (pix[..., 1] < 0) | (pix[..., 1] >= 48)
-    assert outside.any() and not feats[..., 128:][outside].any()
-    dets = det(xyz, inten, img_fts=img, calib=calib)
-    assert len(dets) == 2 and all(d["boxes"].shape[1] == 7 for d in dets)
-    a, b = torch.randn(3, 5, 4, device="cuda"), torch.randn(3, 5, 4, device="cuda")
-    assert torch.equal(fuse_point_image_features(a, b, "mean"), (a + b) / 2.0)
-    assert fuse_point_image_features(a, b, "concat").shape == (3, 5, 8)
-    with pytest.raises(ValueError):
-        fuse_point_image_features(a, b, "max")
 
 
 @pytest.mark.parametrize("workload", ["stack", "rpn_multiclass"])
