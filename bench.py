@@ -500,6 +500,9 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the per-GPU batch (default: 8, or 8 / N with --scaling strong)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the step kernel by kernel (DistributedDataParallel for N > 1) "
                                                             "instead of replaying the captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph whatever the batch (default: the graph below "
+                                                         "8 frames per GPU, where launches bound the step; kernel-by-kernel at 8, "
+                                                         "where the device does and replay measured 3 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-table", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the child runs reported in `extra` (other workload, 1 frame per GPU)")
@@ -657,7 +660,7 @@ def main():
 
     from heterofusionrcnn_amd.graph_step import TrainStep, broadcast_parameters
     from heterofusionrcnn_amd.pipeline import GeometryPrefetcher, choose_group
-    use_graph = not args.no_graph
+    use_graph = (args.graph or per_gpu < B) and not args.no_graph
     group = args.prefetch_group or choose_group(args.steps)
     prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth, group=group)
     lr = dp.scaled_lr(1e-3, world)                                   # optimizer_builder.py:105
@@ -766,7 +769,9 @@ def main():
             if multiclass:
                 # the per-rank shape of BASELINE config 4 (a batch of 8 over 8 GPUs = 1 frame per GPU), and the step without the graph
                 result["extra"]["rpn_multiclass_1_frame_per_gpu"] = _child_bench(["--frames-per-gpu", "1", "--steps", "32"])
-                result["extra"]["rpn_multiclass_eager_launches"] = _child_bench(["--no-graph", "--steps", "8"])
+                result["extra"]["rpn_multiclass_%s" % ("eager_launches" if use_graph else "hip_graph")] = _child_bench(
+                    ["--no-graph" if use_graph else "--graph", "--steps", "20"])
+                result["extra"]["rpn_multiclass_1_frame_per_gpu_eager_launches"] = _child_bench(["--frames-per-gpu", "1", "--no-graph", "--steps", "32"])
                 result["extra"]["rpn_pointnet_train_step"] = _child_bench(["--workload", "rpn", "--steps", "16"])
             elif args.workload == "rpn":
                 result["extra"]["rpn_multiclass_train_step"] = _child_bench(["--workload", "rpn_multiclass", "--steps", "8"])

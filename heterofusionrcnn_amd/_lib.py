@@ -34,6 +34,8 @@ _SIGNATURES = {
     "hf_query_ball_group_xyz": [_i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "hf_ball_query_workspace": [_i, _i],
     "hf_query_ball_group_xyz_ws": [_i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_index_inverse": [_i, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp],
+    "hf_group_point_grad_gather": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_knn_point": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_knn_workspace": [_i, _i],
     "hf_knn_point_sorted": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -54,6 +56,8 @@ _SIGNATURES = {
     "hf_bn_relu_fwd_train": [ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_bn_relu_fwd_eval": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "hf_bn_relu_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_bn_relu_fwd_train_ld": [ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _sz, _vp],
+    "hf_bn_relu_bwd_ld": [ctypes.c_longlong, _i, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_group_concat": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_group_concat_grad": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_three_interpolate_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

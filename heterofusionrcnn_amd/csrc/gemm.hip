@@ -52,9 +52,11 @@ __device__ __forceinline__ float4 load4_guarded(const float *__restrict__ base, 
     }
 }
 
-// per-thread BN affine + ReLU of the four columns a thread stages: y = max(a*x + c, 0)
+// per-thread BN affine + ReLU of the four columns a thread stages: y = max(a (x - mu) + beta, 0) -- the difference first, as the
+// reference graph forms it: a x + (beta - mu a) loses |mu| / sigma digits around y = 0 and flips three times as many ReLU masks
+// against an fp64 evaluation (profiles/r03_grad_noise.md)
 struct ColAct {
-    float a[4], c[4];
+    float a[4], c[4], mu[4];
     bool on;
 };
 
@@ -67,9 +69,11 @@ __device__ __forceinline__ ColAct make_col_act(int col, int ncols, const float *
     for (int i = 0; i < 4; ++i) {
         f.a[i] = 1.f;
         f.c[i] = 0.f;
+        f.mu[i] = 0.f;
         if (f.on && col + i < ncols) {
             f.a[i] = gamma[col + i] * invstd[col + i];
-            f.c[i] = beta[col + i] - mean[col + i] * f.a[i];
+            f.c[i] = beta[col + i];
+            f.mu[i] = mean[col + i];
         }
     }
     return f;
@@ -78,10 +82,10 @@ __device__ __forceinline__ ColAct make_col_act(int col, int ncols, const float *
 __device__ __forceinline__ float4 apply_col_act(const ColAct &f, float4 v, bool inside)
 {
     if (f.on && inside) {  // rows / columns outside the matrix must stay zero
-        v.x = fmaxf(f.a[0] * v.x + f.c[0], 0.f);
-        v.y = fmaxf(f.a[1] * v.y + f.c[1], 0.f);
-        v.z = fmaxf(f.a[2] * v.z + f.c[2], 0.f);
-        v.w = fmaxf(f.a[3] * v.w + f.c[3], 0.f);
+        v.x = fmaxf(f.a[0] * (v.x - f.mu[0]) + f.c[0], 0.f);
+        v.y = fmaxf(f.a[1] * (v.y - f.mu[1]) + f.c[1], 0.f);
+        v.z = fmaxf(f.a[2] * (v.z - f.mu[2]) + f.c[2], 0.f);
+        v.w = fmaxf(f.a[3] * (v.w - f.mu[3]) + f.c[3], 0.f);
     }
     return v;
 }
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     __shared__ float As[kFwdRows * kFwdLS];
     __shared__ float Bs[NT * 32 * kFwdLS];
     __shared__ float red[4][NT * 32][2];
-    __shared__ float sc[kFwdMaxCin], sh[kFwdMaxCin];
+    __shared__ float sc[kFwdMaxCin], sh[kFwdMaxCin], smu[kFwdMaxCin];   // scale, beta, mean
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool act = in_gamma != nullptr;
@@ -246,7 +250,8 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
         for (int k = t; k < cin; k += kGemmThreads) {
             const float a = in_gamma[k] * in_invstd[k];
             sc[k] = a;
-            sh[k] = in_beta[k] - in_mean[k] * a;
+            sh[k] = in_beta[k];
+            smu[k] = in_mean[k];
         }
     }
     __syncthreads();
@@ -279,10 +284,10 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                 if (act) {  // rows / channels outside the matrix stay zero
                     const bool rin = row0 + srow + 32 * p < rows;
                     const int k = kc + k4;
-                    v.x = (rin && k < cin) ? fmaxf(sc[k] * v.x + sh[k], 0.f) : 0.f;
-                    v.y = (rin && k + 1 < cin) ? fmaxf(sc[k + 1] * v.y + sh[k + 1], 0.f) : 0.f;
-                    v.z = (rin && k + 2 < cin) ? fmaxf(sc[k + 2] * v.z + sh[k + 2], 0.f) : 0.f;
-                    v.w = (rin && k + 3 < cin) ? fmaxf(sc[k + 3] * v.w + sh[k + 3], 0.f) : 0.f;
+                    v.x = (rin && k < cin) ? fmaxf(sc[k] * (v.x - smu[k]) + sh[k], 0.f) : 0.f;
+                    v.y = (rin && k + 1 < cin) ? fmaxf(sc[k + 1] * (v.y - smu[k + 1]) + sh[k + 1], 0.f) : 0.f;
+                    v.z = (rin && k + 2 < cin) ? fmaxf(sc[k + 2] * (v.z - smu[k + 2]) + sh[k + 2], 0.f) : 0.f;
+                    v.w = (rin && k + 3 < cin) ? fmaxf(sc[k + 3] * (v.w - smu[k + 3]) + sh[k + 3], 0.f) : 0.f;
                     if (Hout && rin && k < cin) {  // the activated input, kept for the weight gradient
                         float *h = Hout + (row0 + srow + 32 * p) * cin + k;
                         if constexpr (VEC) {
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
         for (int k = t; k < kdim; k += kGemmThreads) {
             const float a = gamma[k] * invstd[k];
             ta[k] = a;
-            tsh[k] = beta[k] - mean[k] * a;
+            tsh[k] = beta[k];
             tmu[k] = mean[k];
             tis[k] = invstd[k];
             tc1[k] = dbeta[k] * inv_r;
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
         pa[nt] = 0.f; psh[nt] = 0.f; pmu[nt] = 0.f; pis[nt] = 0.f; s1[nt] = 0.f; s2[nt] = 0.f;
         if (sums && col < ncols) {
             pa[nt] = p_gamma[col] * p_invstd[col];
-            psh[nt] = p_beta[col] - p_mean[col] * pa[nt];
+            psh[nt] = p_beta[col];
             pmu[nt] = p_mean[col];
             pis[nt] = p_invstd[col];
         }
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                     for (int i = 0; i < 4; ++i) {
                         if (rin && k + i < kdim) {
                             const float a = ta[k + i];
-                            const float dh = (a * zz[i] + tsh[k + i] > 0.0f) ? d[i] : 0.0f;
+                            const float dh = (a * (zz[i] - tmu[k + i]) + tsh[k + i] > 0.0f) ? d[i] : 0.0f;
                             const float xhat = (zz[i] - tmu[k + i]) * tis[k + i];
                             d[i] = a * (dh - tc1[k + i] - xhat * tc2[k + i]);
                         } else {
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                 if (DX) DX[row * ncols + col] = v;
                 if (sums) {
                     const float zp = Zprev[row * ncols + col];
-                    const float dh = (pa[nt] * zp + psh[nt] > 0.0f) ? v : 0.0f;
+                    const float dh = (pa[nt] * (zp - pmu[nt]) + psh[nt] > 0.0f) ? v : 0.0f;
                     s1[nt] += dh;
                     s2[nt] += dh * ((zp - pmu[nt]) * pis[nt]);
                 }

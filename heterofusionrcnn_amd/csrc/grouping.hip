@@ -184,6 +184,44 @@ __global__ void group_point_grad_kernel(int n, int c, long long rows_per_batch, 
     }
 }
 
+// group_point gradient in gather form: for every data point the rows of grad_out that name it (CSR inverse of idx, built
+// with the geometry: hf_index_inverse) are summed in ascending (query, slot) order -- the order of the reference's sequential
+// CPU loop (grouping/test/query_ball_point.cpp:53-66) -- and the point's gradient row is written ONCE: no atomics, no zero
+// fill, deterministic.  c / VEC lanes per data point; grad_out rows have stride `width`, the gathered columns start at `col`.
+template <int VEC>
+__global__ void group_point_grad_gather_kernel(int n, int c, int width, int col, int cv, long long rows_per_batch, long long data_rows,
+                                               const float *__restrict__ grad_out, const int *__restrict__ offsets,
+                                               const int *__restrict__ entries, float *__restrict__ grad_points)
+{
+    const int rows_per_block = blockDim.x / cv;
+    const int cvec = threadIdx.x % cv, rsub = threadIdx.x / cv;
+    if (rsub >= rows_per_block) return;
+    for (long long row = blockIdx.x * static_cast<long long>(rows_per_block) + rsub; row < data_rows;
+         row += static_cast<long long>(gridDim.x) * rows_per_block) {
+        const long long bb = row / n;
+        const int k = static_cast<int>(row - bb * n);
+        const int *off = offsets + bb * (n + 1);
+        const int *ent = entries + bb * rows_per_batch;
+        const float *go = grad_out + bb * rows_per_batch * width + col + cvec * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        const int lo = off[k], hi = off[k + 1];
+        for (int a = lo; a < hi; ++a) {
+            const float *src = go + static_cast<long long>(ent[a]) * width;
+            if constexpr (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(src);
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            } else {
+                acc[0] += src[0];
+            }
+        }
+        float *dst = grad_points + row * c + cvec * VEC;
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else dst[0] = acc[0];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // group_concat: the concat of sample_and_group (pointnet_util.py:58-60) written directly,
 //   out[b,j,k,:] = [ grouped_xyz[b,j,k,0:3], points[b, idx[b,j,k], 0:c], 0 ... ]   (row width `width` >= 3 + c)
@@ -766,6 +804,32 @@ HF_API int hf_group_point_grad_from(int b, int n, int c, int m, int nsample, int
     const int block = 256;
     hipLaunchKernelGGL(group_point_grad_from_kernel, dim3(grid_for(nrows * c, block)), dim3(block), 0, st, n, c, width, col,
                        static_cast<long long>(m) * nsample, nrows, grad_out, idx, grad_points);
+    return launch_status();
+}
+
+HF_API int hf_group_point_grad_gather(int b, int n, int c, int m, int nsample, int width, int col, const float *grad_out,
+                                      const int *offsets, const int *entries, float *grad_points, hf_stream_t stream)
+{
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0 || col < 0 || width < col + c || !offsets || !grad_points) return HF_EINVAL;
+    const long long data_rows = static_cast<long long>(b) * n;
+    if (data_rows == 0) return HF_OK;
+    const long long rpb = static_cast<long long>(m) * nsample;
+    if (rpb > 0 && (!grad_out || !entries)) return HF_EINVAL;
+    const bool vec4 = c % 4 == 0 && width % 4 == 0 && col % 4 == 0 &&
+                      ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_points)) % 16 == 0);
+    const int cv = vec4 ? c / 4 : c;
+    if (cv > 1024) return HF_EINVAL;
+    int block = 256;
+    if (cv > block) block = ((cv + 63) / 64) * 64;
+    const int rows_per_block = block / cv;
+    long long grid = (data_rows + rows_per_block - 1) / rows_per_block;
+    if (grid > kNumCU * 64ll) grid = kNumCU * 64ll;
+    if (vec4)
+        hipLaunchKernelGGL((group_point_grad_gather_kernel<4>), dim3(static_cast<unsigned>(grid)), dim3(block), 0, as_stream(stream), n, c,
+                           width, col, cv, rpb, data_rows, grad_out, offsets, entries, grad_points);
+    else
+        hipLaunchKernelGGL((group_point_grad_gather_kernel<1>), dim3(static_cast<unsigned>(grid)), dim3(block), 0, as_stream(stream), n, c,
+                           width, col, cv, rpb, data_rows, grad_out, offsets, entries, grad_points);
     return launch_status();
 }
 

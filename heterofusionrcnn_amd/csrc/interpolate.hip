@@ -239,9 +239,12 @@ __global__ void three_interpolate_cl_grad_kernel(int m, int c, long long n_per_b
 // One 1024-thread workgroup per cloud: counts and cursors live in LDS (2*m ints).
 // ------------------------------------------------------------------------------------------
 constexpr int kInvThreads = 1024;
-constexpr int kInvMaxKnown = 8192;
+constexpr int kInvMaxKnown = 8192;        // three_nn_inverse (ABI limit kept); the general form takes up to kInvMaxTargets
+constexpr int kInvMaxTargets = 19968;     // 2 ints of LDS per target: 156 KB
 
-__global__ __launch_bounds__(kInvThreads) void three_nn_inverse_kernel(int n, int m, const int *__restrict__ idx,
+// `total` index values per cloud, each in [0, m): the CSR inverse (for every target the flat positions that name it, ascending).
+// three_nn: total = 3 n; group_point / kNN tables: total = queries * nsample.
+__global__ __launch_bounds__(kInvThreads) void three_nn_inverse_kernel(long long total, int m, const int *__restrict__ idx,
                                                                        int *__restrict__ offsets,
                                                                        int *__restrict__ entries)
 {
@@ -249,7 +252,6 @@ __global__ __launch_bounds__(kInvThreads) void three_nn_inverse_kernel(int n, in
     __shared__ int wsum[16];
     int *cnt = inv_lds, *cur = inv_lds + m;
     const int b = blockIdx.x, t = threadIdx.x;
-    const long long total = 3ll * n;
     const int *ib = idx + b * total;
     int *off = offsets + static_cast<long long>(b) * (m + 1);
     int *ent = entries + b * total;
@@ -435,7 +437,23 @@ HF_API int hf_three_nn_inverse(int b, int n, int m, const int *idx, int *offsets
     if (b == 0) return HF_OK;
     if (static_cast<long long>(n) * 3 > 0x7fffffffll) return HF_EINVAL;
     hipLaunchKernelGGL(three_nn_inverse_kernel, dim3(b), dim3(kInvThreads), sizeof(int) * 2 * static_cast<size_t>(m),
-                       as_stream(stream), n, m, idx, offsets, entries);
+                       as_stream(stream), 3ll * n, m, idx, offsets, entries);
+    return launch_status();
+}
+
+HF_API int hf_index_inverse(int b, long long total, int m, const int *idx, int *offsets, int *entries, hf_stream_t stream)
+{
+    if (b < 0 || total < 0 || m <= 0 || m > kInvMaxTargets || total > 0x7fffffffll || !offsets || (total > 0 && (!idx || !entries)))
+        return HF_EINVAL;
+    if (b == 0) return HF_OK;
+    const size_t lds = sizeof(int) * 2 * static_cast<size_t>(m);
+    static bool raised = false;   // raise the dynamic-LDS limit once, not on every launch
+    if (lds > 48 * 1024 && !raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&three_nn_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 512);
+        raised = true;
+    }
+    hipLaunchKernelGGL(three_nn_inverse_kernel, dim3(b), dim3(kInvThreads), lds, as_stream(stream), total, m, idx, offsets, entries);
     return launch_status();
 }
 

@@ -161,16 +161,17 @@ template <int VEC>
 __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                 const float *__restrict__ x, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, const float *__restrict__ mean,
-                                const float *__restrict__ invstd, int relu, float *__restrict__ y)
+                                const float *__restrict__ invstd, int relu, float *__restrict__ y, long long ldy)
 {
     const int t = threadIdx.x;
     const int cvec = t % cv, rsub = t / cv;
-    float a[VEC], b[VEC];
+    float a[VEC], b[VEC], mu[VEC];   // y = a (x - mu) + beta: the difference first, as the reference graph forms it
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         const int ch = cvec * VEC + i;
         a[i] = gamma[ch] * invstd[ch];
-        b[i] = beta[ch] - mean[ch] * a[i];
+        b[i] = beta[ch];
+        mu[i] = mean[ch];
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
@@ -181,11 +182,11 @@ __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long lon
         for (int i = 0; i < VEC; ++i) {
             float xv = vget<VEC>(v, i);
             if (relu & kBnEluIn) xv = elu_fwd(xv);
-            float h = a[i] * xv + b[i];
+            float h = a[i] * (xv - mu[i]) + b[i];
             if (relu & kBnRelu) h = fmaxf(h, 0.0f);
             vset<VEC>(o, i, h);
         }
-        stv<VEC>(y + r * c + cvec * VEC, o);
+        stv<VEC>(y + r * ldy + cvec * VEC, o);   // ldy >= c: the row may be a slice of a wider (concat) buffer
     }
 }
 
@@ -195,7 +196,7 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
                                      const float *__restrict__ x, const float *__restrict__ dy,
                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                      const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                                     float *__restrict__ partial)
+                                     float *__restrict__ partial, long long lddy)
 {
     extern __shared__ float smem[];
     const int t = threadIdx.x;
@@ -206,20 +207,20 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
         const int ch = cvec * VEC + i;
         mu[i] = mean[ch]; is[i] = invstd[ch];
         a[i] = gamma[ch] * is[i];
-        b[i] = beta[ch] - mu[i] * a[i];
+        b[i] = beta[ch];
         s1[i] = 0.f; s2[i] = 0.f;
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     for (long long r = r0 + rsub; r < r1; r += rpb) {
         const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
-        const typename VecT<VEC>::type g = ldv<VEC>(dy + r * c + cvec * VEC);
+        const typename VecT<VEC>::type g = ldv<VEC>(dy + r * lddy + cvec * VEC);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float xv = vget<VEC>(v, i);
             if (relu & kBnEluIn) xv = elu_fwd(xv);
             float dh = vget<VEC>(g, i);
-            if ((relu & kBnRelu) && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
+            if ((relu & kBnRelu) && !(a[i] * (xv - mu[i]) + b[i] > 0.0f)) dh = 0.0f;
             s1[i] += dh;
             s2[i] += dh * ((xv - mu[i]) * is[i]);
         }
@@ -252,7 +253,7 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                  const float *__restrict__ mean, const float *__restrict__ invstd,
                                  const float *__restrict__ dgamma, const float *__restrict__ dbeta, int relu,
-                                 float *__restrict__ dx, float *__restrict__ colsum_partial)
+                                 float *__restrict__ dx, float *__restrict__ colsum_partial, long long lddy)
 {
     extern __shared__ float smem[];
     const int t = threadIdx.x;
@@ -264,7 +265,7 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
         const int ch = cvec * VEC + i;
         mu[i] = mean[ch]; is[i] = invstd[ch];
         a[i] = gamma[ch] * is[i];
-        b[i] = beta[ch] - mu[i] * a[i];
+        b[i] = beta[ch];
         c1[i] = dbeta[ch] * inv_r;
         c2[i] = dgamma[ch] * inv_r;
         cs[i] = 0.f; unused[i] = 0.f;
@@ -273,14 +274,14 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     for (long long r = r0 + rsub; r < r1; r += rpb) {
         const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
-        const typename VecT<VEC>::type g = ldv<VEC>(dy + r * c + cvec * VEC);
+        const typename VecT<VEC>::type g = ldv<VEC>(dy + r * lddy + cvec * VEC);
         typename VecT<VEC>::type o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const float xraw = vget<VEC>(v, i);
             const float xv = (relu & kBnEluIn) ? elu_fwd(xraw) : xraw;
             float dh = vget<VEC>(g, i);
-            if ((relu & kBnRelu) && !(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
+            if ((relu & kBnRelu) && !(a[i] * (xv - mu[i]) + b[i] > 0.0f)) dh = 0.0f;
             const float xhat = (xv - mu[i]) * is[i];
             float d = a[i] * (dh - c1[i] - xhat * c2[i]);
             if (relu & kBnEluIn) d = d * elu_slope(xraw);
@@ -323,12 +324,13 @@ __global__ void bn_pool_fwd_kernel(long long groups, int k, int c, int cv, int r
 {
     const int t = threadIdx.x;
     const int cvec = t % cv, rsub = t / cv;
-    float a[VEC], b[VEC];
+    float a[VEC], b[VEC], mu[VEC];   // y = a (x - mu) + beta: the difference first, as the reference graph forms it
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         const int ch = cvec * VEC + i;
         a[i] = gamma[ch] * invstd[ch];
-        b[i] = beta[ch] - mean[ch] * a[i];
+        b[i] = beta[ch];
+        mu[i] = mean[ch];
     }
     const long long g0 = blockIdx.x * groups_per_block;
     const long long g1 = g0 + groups_per_block < groups ? g0 + groups_per_block : groups;
@@ -342,7 +344,7 @@ __global__ void bn_pool_fwd_kernel(long long groups, int k, int c, int cv, int r
             const typename VecT<VEC>::type v = ldv<VEC>(zg + static_cast<long long>(kk) * c);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                const float h = fmaxf(a[i] * vget<VEC>(v, i) + b[i], 0.0f);
+                const float h = fmaxf(a[i] * (vget<VEC>(v, i) - mu[i]) + b[i], 0.0f);
                 if (h > best[i]) { best[i] = h; bk[i] = kk; }  // first maximum wins
             }
         }
@@ -371,7 +373,7 @@ __global__ void bn_pool_bwd_reduce_kernel(long long groups, int k, int c, int cv
         const int ch = cvec * VEC + i;
         mu[i] = mean[ch]; is[i] = invstd[ch];
         a[i] = gamma[ch] * is[i];
-        b[i] = beta[ch] - mu[i] * a[i];
+        b[i] = beta[ch];
         s1[i] = 0.f; s2[i] = 0.f;
     }
     const long long g0 = blockIdx.x * groups_per_block;
@@ -383,7 +385,7 @@ __global__ void bn_pool_bwd_reduce_kernel(long long groups, int k, int c, int cv
             const int kk = argmax[g * c + ch];
             const float xv = z[(g * k + kk) * c + ch];
             float dh = dpooled[g * c + ch];
-            if (!(a[i] * xv + b[i] > 0.0f)) dh = 0.0f;
+            if (!(a[i] * (xv - mu[i]) + b[i] > 0.0f)) dh = 0.0f;
             s1[i] += dh;
             s2[i] += dh * ((xv - mu[i]) * is[i]);
         }
@@ -418,7 +420,7 @@ __global__ void bn_pool_bwd_dx_kernel(long long rows, int k, int c, int cv, int 
         const int ch = cvec * VEC + i;
         mu[i] = mean[ch]; is[i] = invstd[ch];
         a[i] = gamma[ch] * is[i];
-        b[i] = beta[ch] - mu[i] * a[i];
+        b[i] = beta[ch];
         c1[i] = dbeta[ch] * inv_r;
         c2[i] = dgamma[ch] * inv_r;
         cs[i] = 0.f; unused[i] = 0.f;
@@ -435,7 +437,7 @@ __global__ void bn_pool_bwd_dx_kernel(long long rows, int k, int c, int cv, int 
         for (int i = 0; i < VEC; ++i) {
             const float xv = vget<VEC>(v, i);
             float dh = 0.0f;
-            if (argmax[g * c + cvec * VEC + i] == kk && a[i] * xv + b[i] > 0.0f) dh = vget<VEC>(dp, i);
+            if (argmax[g * c + cvec * VEC + i] == kk && a[i] * (xv - mu[i]) + b[i] > 0.0f) dh = vget<VEC>(dp, i);
             const float xhat = (xv - mu[i]) * is[i];
             const float d = a[i] * (dh - c1[i] - xhat * c2[i]);
             cs[i] += d;
@@ -477,15 +479,18 @@ HF_API size_t hf_bn_workspace(long long rows, int c)
     return sizeof(float) * 2 * static_cast<size_t>(c) * kBnMaxBlocks;
 }
 
-HF_API int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps,
-                                float momentum, float *running_mean, float *running_var, int relu, float *y,
-                                float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
-                                hf_stream_t stream)
+// vec = 4 needs 16-byte rows on every strided operand too
+static bool ld_ok4(long long ld) { return ld % 4 == 0; }
+
+HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps,
+                                   float momentum, float *running_mean, float *running_var, int relu, float *y, long long ldy,
+                                   float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
+                                   hf_stream_t stream)
 {
-    if (rows <= 0 || c <= 0 || c > 4096 || !x || !gamma || !beta || !y || !save_mean || !save_invstd) return HF_EINVAL;
+    if (rows <= 0 || c <= 0 || c > 4096 || ldy < c || !x || !gamma || !beta || !y || !save_mean || !save_invstd) return HF_EINVAL;
     if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
     BnGeom g = bn_geom(rows, c);
-    if (g.vec == 4 && !(aligned16(x) && aligned16(y))) return HF_EINVAL;
+    if (g.vec == 4 && !(aligned16(x) && aligned16(y) && ld_ok4(ldy))) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
@@ -499,11 +504,20 @@ HF_API int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const flo
                        momentum, running_mean, running_var, save_mean, save_invstd);
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y);
+                           g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
     else
         hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y);
+                           g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
     return launch_status();
+}
+
+HF_API int hf_bn_relu_fwd_train(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps,
+                                float momentum, float *running_mean, float *running_var, int relu, float *y,
+                                float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
+                                hf_stream_t stream)
+{
+    return hf_bn_relu_fwd_train_ld(rows, c, x, gamma, beta, eps, momentum, running_mean, running_var, relu, y, c, save_mean,
+                                   save_invstd, workspace, workspace_bytes, stream);
 }
 
 HF_API int hf_bn_stats(long long rows, int c, const float *x, float eps, float momentum, float *running_mean,
@@ -536,10 +550,43 @@ HF_API int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const floa
     hipStream_t st = as_stream(stream);
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, gamma, beta, mean, invstd, relu, y);
+                           g.rows_per_block, x, gamma, beta, mean, invstd, relu, y, static_cast<long long>(c));
     else
         hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, gamma, beta, mean, invstd, relu, y);
+                           g.rows_per_block, x, gamma, beta, mean, invstd, relu, y, static_cast<long long>(c));
+    return launch_status();
+}
+
+HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float *dy, long long lddy, const float *gamma,
+                             const float *beta, const float *save_mean, const float *save_invstd, int relu, float *dx,
+                             float *dgamma, float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes,
+                             hf_stream_t stream)
+{
+    if (rows <= 0 || c <= 0 || c > 4096 || lddy < c || !x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma ||
+        !dbeta)
+        return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx) && ld_ok4(lddy))) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, partial, dgamma, dbeta);
+    float *cpart = dx_colsum ? partial : nullptr;  // the reduce partials were consumed by the finalize kernel above
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy);
+    else
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy);
+    if (dx_colsum)
+        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, cpart, dx_colsum);
     return launch_status();
 }
 
@@ -547,32 +594,8 @@ HF_API int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy
                           const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                           float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream)
 {
-    if (rows <= 0 || c <= 0 || c > 4096 || !x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma ||
-        !dbeta)
-        return HF_EINVAL;
-    if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
-    BnGeom g = bn_geom(rows, c);
-    if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx))) return HF_EINVAL;
-    hipStream_t st = as_stream(stream);
-    float *partial = static_cast<float *>(workspace);
-    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial);
-    else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, partial, dgamma, dbeta);
-    float *cpart = dx_colsum ? partial : nullptr;  // the reduce partials were consumed by the finalize kernel above
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart);
-    else
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart);
-    if (dx_colsum)
-        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, cpart, dx_colsum);
-    return launch_status();
+    return hf_bn_relu_bwd_ld(rows, c, x, dy, c, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, dx_colsum, workspace,
+                             workspace_bytes, stream);
 }
 
 HF_API int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
@@ -589,11 +612,11 @@ HF_API int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float 
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
                            g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx,
-                           static_cast<float *>(nullptr));
+                           static_cast<float *>(nullptr), static_cast<long long>(c));
     else
         hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
                            g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx,
-                           static_cast<float *>(nullptr));
+                           static_cast<float *>(nullptr), static_cast<long long>(c));
     return launch_status();
 }
 

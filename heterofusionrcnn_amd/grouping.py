@@ -74,12 +74,29 @@ def group_point(points, idx):
     return _GroupPoint.apply(points, idx)
 
 
+INVERSE_MAX_TARGETS = 19968
+
+
+def index_inverse(idx, n):
+    """idx (B,M,K) int32 with values in [0, n) -> (offsets (B,n+1), entries (B,M*K)) int32: for every data point the flat
+    (query*K + slot) positions that name it, ascending.  Coordinates-only, so it is prepared with the geometry
+    (pipeline.GeometryPrefetcher); the gradient of group_point / concat_group then gathers instead of scattering atomics."""
+    idx = dev_tensor(idx, torch.int32, "idx")
+    require(idx.dim() == 3, "index_inverse expects (b,m,k) idx shape")
+    require(0 < n <= INVERSE_MAX_TARGETS, "index_inverse expects 0 < n <= %d" % INVERSE_MAX_TARGETS)
+    b, m, k = idx.shape
+    offsets = torch.empty((b, n + 1), dtype=torch.int32, device=idx.device)
+    entries = torch.empty((b, m * k), dtype=torch.int32, device=idx.device)
+    check(_lib.lib().hf_index_inverse(b, m * k, n, ptr(idx), ptr(offsets), ptr(entries), stream_ptr()), "index_inverse")
+    return offsets, entries
+
+
 class _ConcatGroup(torch.autograd.Function):
     """[head | points[idx]]: the gathered part is written straight into the concat buffer and its gradient is read out
     of the concat's gradient in place (hf_group_point_into / hf_group_point_grad_from); only `head` is copied"""
 
     @staticmethod
-    def forward(ctx, head, points, idx):
+    def forward(ctx, head, points, idx, offsets, entries):
         b, n, c = points.shape
         _, m, ns = idx.shape
         ch = head.shape[-1]
@@ -87,31 +104,38 @@ class _ConcatGroup(torch.autograd.Function):
         out[..., :ch].copy_(head)
         check(_lib.lib().hf_group_point_into(b, n, c, m, ns, ch + c, ch, ptr(points), ptr(idx), ptr(out), stream_ptr()),
               "group_point_into")
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(idx, *([offsets, entries] if offsets is not None else []))
         ctx.shape = (b, n, c, ch)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
         b, n, c, ch = ctx.shape
         _, m, ns = idx.shape
         grad_out = grad_out.contiguous()
         g = None
         if ctx.needs_input_grad[1]:
             g = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
-            check(_lib.lib().hf_group_point_grad_from(b, n, c, m, ns, ch + c, ch, ptr(grad_out), ptr(idx), ptr(g), stream_ptr()),
-                  "group_point_grad_from")
-        return (grad_out[..., :ch] if ctx.needs_input_grad[0] else None), g, None
+            if len(ctx.saved_tensors) == 3:   # the inverse index came with the geometry: gather, every row written once
+                offsets, entries = ctx.saved_tensors[1:]
+                check(_lib.lib().hf_group_point_grad_gather(b, n, c, m, ns, ch + c, ch, ptr(grad_out), ptr(offsets), ptr(entries),
+                                                            ptr(g), stream_ptr()), "group_point_grad_gather")
+            else:
+                check(_lib.lib().hf_group_point_grad_from(b, n, c, m, ns, ch + c, ch, ptr(grad_out), ptr(idx), ptr(g), stream_ptr()),
+                      "group_point_grad_from")
+        return (grad_out[..., :ch] if ctx.needs_input_grad[0] else None), g, None, None, None
 
 
-def concat_group(head, points, idx):
-    """torch.cat([head, group_point(points, idx)], -1) for head (B,M,K,Ch), points (B,N,C), idx (B,M,K)"""
+def concat_group(head, points, idx, inverse=None):
+    """torch.cat([head, group_point(points, idx)], -1) for head (B,M,K,Ch), points (B,N,C), idx (B,M,K);
+    inverse = index_inverse(idx, N) (optional): the gradient w.r.t. points gathers instead of using atomics"""
     require(head.dim() == 4 and points.dim() == 3 and idx.dim() == 3 and head.shape[:3] == idx.shape,
             "concat_group expects head (B,M,K,Ch), points (B,N,C), idx (B,M,K)")
     points = dev_tensor(points, torch.float32, "points")
     idx = dev_tensor(idx, torch.int32, "idx")
-    return _ConcatGroup.apply(head, points, idx)
+    offsets, entries = inverse if inverse is not None else (None, None)
+    return _ConcatGroup.apply(head, points, idx, offsets, entries)
 
 
 class _GroupConcat(torch.autograd.Function):

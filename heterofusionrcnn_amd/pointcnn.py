@@ -30,7 +30,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .grouping import concat_group, group_point, knn_point
+from .grouping import INVERSE_MAX_TARGETS, concat_group, group_point, index_inverse, knn_point
 from .sampling import farthest_point_sample, gather_point
 from .mlp import BatchNormReLU, linear_nobias
 
@@ -61,6 +61,103 @@ class Dense(nn.Module):
 
     def forward(self, x):
         return self.post(linear_nobias(x, self.linear.weight))
+
+
+def _bn_mode(bn):
+    return (1 if bn.relu else 0) | (2 if bn.elu_in else 0)
+
+
+def _bn_ws(rows, c, device):
+    nbytes = _lib.lib().hf_bn_workspace(rows, c)
+    return torch.empty((nbytes // 4,), dtype=torch.float32, device=device), nbytes
+
+
+class _BNConcatGroup(torch.autograd.Function):
+    """[bn(elu(z)) | points[idx]] for z (B*M*K, Ch), points (B,N,C), idx (B,M,K) -> (B,M,K,Ch+C): the BatchNorm of the lifting
+    layer writes its output straight into the concat buffer of pointcnn.py:104 (row stride Ch+C) and the gather fills the
+    rest; backward reads both halves of the concat's gradient in place.  No tf.concat copy in either direction."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, mode, points, idx, offsets, entries):
+        L = _lib.lib()
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        rows, ch = z.shape
+        width = ch + c
+        out = torch.empty((b, m, ns, width), dtype=torch.float32, device=z.device)
+        mean = torch.empty((ch,), dtype=torch.float32, device=z.device)
+        invstd = torch.empty((ch,), dtype=torch.float32, device=z.device)
+        ws, nbytes = _bn_ws(rows, ch, z.device)
+        check(L.hf_bn_relu_fwd_train_ld(rows, ch, ptr(z), ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var),
+                                        mode, ptr(out), width, ptr(mean), ptr(invstd), ptr(ws), nbytes, stream_ptr()), "bn_relu_fwd_train_ld")
+        check(L.hf_group_point_into(b, n, c, m, ns, width, ch, ptr(points), ptr(idx), ptr(out), stream_ptr()), "group_point_into")
+        ctx.save_for_backward(z, gamma, beta, mean, invstd, idx, *([offsets, entries] if offsets is not None else []))
+        ctx.meta = (b, n, c, m, ns, ch, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.lib()
+        z, gamma, beta, mean, invstd, idx = ctx.saved_tensors[:6]
+        b, n, c, m, ns, ch, mode = ctx.meta
+        rows, width = z.shape[0], ch + c
+        go = go.contiguous()
+        dz = torch.empty_like(z)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        ws, nbytes = _bn_ws(rows, ch, z.device)
+        check(L.hf_bn_relu_bwd_ld(rows, ch, ptr(z), ptr(go), width, ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), mode, ptr(dz),
+                                  ptr(dgamma), ptr(dbeta), None, ptr(ws), nbytes, stream_ptr()), "bn_relu_bwd_ld")
+        g = None
+        if ctx.needs_input_grad[8]:
+            g = torch.empty((b, n, c), dtype=torch.float32, device=z.device)
+            if len(ctx.saved_tensors) == 8:
+                offsets, entries = ctx.saved_tensors[6:]
+                check(L.hf_group_point_grad_gather(b, n, c, m, ns, width, ch, ptr(go), ptr(offsets), ptr(entries), ptr(g), stream_ptr()),
+                      "group_point_grad_gather")
+            else:
+                check(L.hf_group_point_grad_from(b, n, c, m, ns, width, ch, ptr(go), ptr(idx), ptr(g), stream_ptr()),
+                      "group_point_grad_from")
+        return dz, dgamma, dbeta, None, None, None, None, None, g, None, None, None
+
+
+class _BNConcatSkip(torch.autograd.Function):
+    """[bn(elu(z)) | skip] for z (R, C), skip (R, Cs) -> (R, C+Cs): the X-DeConv output normalised straight into the concat with
+    the encoder's skip features (pointcnn.py:349); backward reads its half of the gradient in place, the skip's half is a view."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, mode, skip):
+        L = _lib.lib()
+        rows, c = z.shape
+        cs = skip.shape[1]
+        out = torch.empty((rows, c + cs), dtype=torch.float32, device=z.device)
+        mean = torch.empty((c,), dtype=torch.float32, device=z.device)
+        invstd = torch.empty((c,), dtype=torch.float32, device=z.device)
+        ws, nbytes = _bn_ws(rows, c, z.device)
+        check(L.hf_bn_relu_fwd_train_ld(rows, c, ptr(z), ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var),
+                                        mode, ptr(out), c + cs, ptr(mean), ptr(invstd), ptr(ws), nbytes, stream_ptr()), "bn_relu_fwd_train_ld")
+        out[:, c:].copy_(skip)
+        ctx.save_for_backward(z, gamma, beta, mean, invstd)
+        ctx.meta = (c, cs, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.lib()
+        z, gamma, beta, mean, invstd = ctx.saved_tensors
+        c, cs, mode = ctx.meta
+        rows = z.shape[0]
+        go = go.contiguous()
+        dz = torch.empty_like(z)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        ws, nbytes = _bn_ws(rows, c, z.device)
+        check(L.hf_bn_relu_bwd_ld(rows, c, ptr(z), ptr(go), c + cs, ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), mode, ptr(dz),
+                                  ptr(dgamma), ptr(dbeta), None, ptr(ws), nbytes, stream_ptr()), "bn_relu_bwd_ld")
+        return dz, dgamma, dbeta, None, None, None, None, None, (go[:, c:] if ctx.needs_input_grad[8] else None)
+
+
+def _fusable(bn, ref, ch, width):
+    """the strided BatchNorm passes: training mode on the device; 16-byte rows on both sides when the channels are vectorised"""
+    return bn.training and ref.is_cuda and ref.dtype == torch.float32 and (ch % 4 != 0 or width % 4 == 0)
 
 
 _XAPPLY_K = (4, 8)                                             # K with a HIP kernel (csrc/xconv.hip); shipped configs: 8
@@ -240,24 +337,40 @@ class XConv(nn.Module):
             _, idx = knn_point(self.k * self.d, pts, qrs)
             return idx[:, :, ::self.d].contiguous() if self.d > 1 else idx
 
-    def forward(self, pts, fts, qrs, idx=None):
+    def forward(self, pts, fts, qrs, idx=None, inverse=None, skip=None):
+        """inverse = index_inverse(idx, N) prepared with the geometry: the gradient of the feature gather then gathers too.
+        skip (B,P,Cs): returns [x-conv output | skip] (the concat of an X-DeConv with the encoder features, pointcnn.py:349)"""
         idx = idx if idx is not None else self.neighbours(pts, qrs)
         b, p, k = idx.shape
         local = group_point(pts, idx) - qrs.unsqueeze(2)     # (B,P,K,3)  P' <- P - p
-        f = self.lift1(self.lift0(local))                     # F_delta
-        if fts is not None:
-            f = concat_group(f, fts, idx)                      # F_* <- [F_delta, F]: gathered straight into the concat
+        bn1 = self.lift1.post.bn
+        if fts is not None and _fusable(bn1, fts, self.lift1.linear.out_features, self.lift1.linear.out_features + fts.shape[-1]):
+            # F_* <- [F_delta, F]: the second lifting layer's BatchNorm writes into the concat, the gather fills the rest
+            z = linear_nobias(self.lift0(local), self.lift1.linear.weight)
+            off, ent = inverse if inverse is not None else (None, None)
+            f = _BNConcatGroup.apply(z.reshape(-1, z.shape[-1]), bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps,
+                                     bn1.momentum, _bn_mode(bn1), fts.contiguous(), idx, off, ent)
+        else:
+            f = self.lift1(self.lift0(local))                 # F_delta
+            if fts is not None:
+                f = concat_group(f, fts, idx, inverse)         # F_* <- [F_delta, F]: gathered straight into the concat
         if self.with_x:
             x = self.x0(local.reshape(b, p, 1, k * 3)).reshape(b, p, k, k)
             x = self.x1(x).reshape(b, p, k, k)
             x = self.x2(x).reshape(b, p, k, k)
             # F_X <- X x F_*, then the depthwise half of the separable convolution, in one pass
-            out = self.conv.post(linear_nobias(xconv_depthwise(x, f, self.conv.depthwise), self.conv.pointwise.weight))
+            zc = linear_nobias(xconv_depthwise(x, f, self.conv.depthwise), self.conv.pointwise.weight)
+            bnc = self.conv.post.bn
+            if skip is not None and not self.with_global and _fusable(bnc, zc, zc.shape[-1], zc.shape[-1] + skip.shape[-1]):
+                out = _BNConcatSkip.apply(zc.reshape(-1, zc.shape[-1]), bnc.weight, bnc.bias, bnc.running_mean, bnc.running_var, bnc.eps,
+                                          bnc.momentum, _bn_mode(bnc), skip.reshape(-1, skip.shape[-1]).contiguous())
+                return out.reshape(b, p, -1)
+            out = self.conv.post(zc)
         else:
             out = self.conv(f)                                # (B,P,C)
         if self.with_global:
             out = torch.cat([self.g1(self.g0(qrs)), out], dim=-1)
-        return out
+        return out if skip is None else torch.cat([out, skip], dim=-1)
 
 
 @dataclass
@@ -322,19 +435,24 @@ class PointCnnBackbone(nn.Module):
                 enc_idx.append(self.enc[li].neighbours(cur, qrs))
                 pts.append(qrs)
             dec_idx = [self.dec[li].neighbours(pts[pi + 1], pts[qi + 1]) for li, (k, d, pi, qi) in enumerate(self.cfg.xdconv)]
-        return {"pts": pts, "enc": enc_idx, "dec": dec_idx}
+            # the inverse of every neighbour table (for each data point the (query, slot) pairs that name it): the gradient of
+            # the feature gather then writes every row once instead of scattering atomics
+            inv = lambda idx, n: index_inverse(idx, n) if n <= INVERSE_MAX_TARGETS else None
+            enc_inv = [inv(ix, pts[li].shape[1]) for li, ix in enumerate(enc_idx)]
+            dec_inv = [inv(ix, pts[pi + 1].shape[1]) for ix, (k, d, pi, qi) in zip(dec_idx, self.cfg.xdconv)]
+        return {"pts": pts, "enc": enc_idx, "dec": dec_idx, "enc_inv": enc_inv, "dec_inv": dec_inv}
 
     def forward(self, xyz, features, geometry=None):
         g = geometry if geometry is not None else self.geometry(xyz)
         pts = g["pts"]
         fts = [features]
         for li, m in enumerate(self.enc):
-            fts.append(m(pts[li], fts[-1], pts[li + 1], g["enc"][li]))
+            fts.append(m(pts[li], fts[-1], pts[li + 1], g["enc"][li], g.get("enc_inv", [None] * len(self.enc))[li]))
         cur = None
         for li, (k, d, pi, qi) in enumerate(self.cfg.xdconv):
             src = fts[pi + 1] if li == 0 else cur
-            x = self.dec[li](pts[pi + 1], src, pts[qi + 1], g["dec"][li])
-            cur = self.fuse[li](torch.cat([x, fts[qi + 1]], dim=-1))
+            x = self.dec[li](pts[pi + 1], src, pts[qi + 1], g["dec"][li], g.get("dec_inv", [None] * len(self.dec))[li], skip=fts[qi + 1])
+            cur = self.fuse[li](x)                                   # x = [x-deconv | encoder features of the query layer]
         out = cur if cur is not None else fts[-1]        # no decoder (the RCNN's extractor): the last encoder layer
         for layer, rate in zip(self.fc, self.fc_drop):
             out = F.dropout(layer(out), p=rate, training=self.training)                                   # :371-384

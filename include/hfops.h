@@ -92,6 +92,17 @@ int hf_group_point(int b, int n, int c, int m, int nsample, const float *points,
 int hf_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
                         float *grad_points, hf_stream_t stream);
 
+/* The CSR inverse of an index tensor, built with the geometry (coordinates only): idx holds `total` values per cloud, each in
+ * [0, m) (group_point / kNN tables: total = queries * nsample; three_nn: total = 3 n).  offsets (b, m+1), entries (b, total):
+ * for every target the flat positions that name it, ascending.  m <= 19968 (two LDS words per target).
+ * hf_group_point_grad_gather: the gradient of hf_group_point / hf_group_point_into over that inverse -- every data point sums
+ * the grad_out rows that name it in ascending (query, slot) order (the order of the reference's CPU loop,
+ * grouping/test/query_ball_point.cpp:53-66) and its row is written once: no atomics, no zero fill, deterministic.
+ * grad_out rows have stride `width`, the gathered columns start at `col` (width = c, col = 0 for plain group_point). */
+int hf_index_inverse(int b, long long total, int m, const int *idx, int *offsets, int *entries, hf_stream_t stream);
+int hf_group_point_grad_gather(int b, int n, int c, int m, int nsample, int width, int col, const float *grad_out,
+                               const int *offsets, const int *entries, float *grad_points, hf_stream_t stream);
+
 /* Fused query_ball_point + group_point(xyz) in ONE launch: the pair of calls at
  * hf/core/feature_extractors/pointnet_util.py:48-49,258-259.  Outputs are exactly those of the
  * two separate ops; grouped_xyz (b,m,nsample,3) optionally has the query subtracted
@@ -226,6 +237,16 @@ int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const float *gamm
 int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
                    const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
                    float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+/* The same two passes with ROW STRIDES on the normalised tensor: y (forward) / dy (backward) may be a column slice of a wider
+ * buffer (ld floats per row, ld >= c; 16-byte rows when c % 4 == 0).  That is how a BatchNorm output lands directly inside
+ * the concat the reference builds next (pointcnn.py:104, :349: [lifted | gathered], [x-conv | skip]) and how its gradient is
+ * read out of the concat's gradient in place: no tf.concat copy in either direction. */
+int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps,
+                            float momentum, float *running_mean, float *running_var, int relu, float *y, long long ldy,
+                            float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float *dy, long long lddy, const float *gamma,
+                      const float *beta, const float *save_mean, const float *save_invstd, int relu, float *dx, float *dgamma,
+                      float *dbeta, float *dx_colsum, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
 /* knn_point (see hf_knn_point) with a scratch buffer: the data points of every cloud are binned into a 2-D grid over
  * its two widest axes first; each query then searches rings of cells around its own and stops once everything outside

@@ -60,6 +60,27 @@ if os.environ.get("NO_MFMA_FWD"):
     _mlp._mfma_forward_pays = lambda *a: False
 if os.environ.get("NO_SPLITK"):
     _mlp._splitk_wgrad = lambda g, x, chunk=None: g.t() @ x
+if os.environ.get("NO_CHAIN"):
+    # layer-by-layer nodes (library GEMM + hf_bn_relu_* passes per layer) instead of the one-node shared MLP
+    def nochain(x, pool_k, layers, *params):
+        n = len(layers)
+        for i, l in enumerate(layers):
+            w, b = params[4 * i], params[4 * i + 1]
+            args = (x, w, b, l.bn.weight, l.bn.bias, l.bn.running_mean, l.bn.running_var, l.bn.eps, l.bn.momentum)
+            x = _mlp._LinearBNReLUMaxPool.apply(*args, pool_k) if (pool_k and i == n - 1) else _mlp._LinearBNReLU.apply(*args, True)
+        return x
+    _mlp._SharedMLPChain.apply = staticmethod(nochain)
+if os.environ.get("TORCH_BN"):
+    # ... and the BatchNorm of every layer by torch ops (two-pass variance, autograd's backward)
+    def torchbn(x, pool_k, layers, *params):
+        n = len(layers)
+        for i, l in enumerate(layers):
+            w, b = params[4 * i], params[4 * i + 1]
+            z = F.linear(x, w, b)
+            mu, var = z.mean(0), z.var(0, unbiased=False)
+            x = torch.relu((z - mu) / torch.sqrt(var + l.bn.eps) * l.bn.weight + l.bn.bias)
+        return x.view(-1, pool_k, x.shape[-1]).max(dim=1).values if pool_k else x
+    _mlp._SharedMLPChain.apply = staticmethod(torchbn)
 out = model(xyz, inten, geometry=model.geometry(xyz))
 ga = torch.autograd.grad(out, params, g_out, allow_unused=True)
 r32 = stack_ref(torch.float32)
@@ -69,10 +90,12 @@ gc = torch.autograd.grad(r64, params, g_out.double(), allow_unused=True)
 print("output: fused vs fp64 %.3e, torch32 vs fp64 %.3e" % (float((out - r64).abs().max()), float((r32 - r64).abs().max())))
 print("%-26s %10s %12s %12s" % ("parameter", "scale", "fused-fp64", "torch32-fp64"))
 for (n, _), a, b, c in zip(model.named_parameters(), ga, gb, gc):
-    if n.endswith("fc.bias") or not n.startswith(("sa.0", "sa.1")):
+    if n.endswith("fc.bias"):
         continue
     c32 = c.float()
     z = torch.zeros_like(c32)
     a = z if a is None else a
     b = z if b is None else b
-    print("%-26s %10.3e %12.3e %12.3e" % (n, float(c32.abs().max()), float((a - c32).abs().max()), float((b - c32).abs().max())))
+    sc = float(c32.abs().max())
+    print("%-26s %10.3e %12.3e %12.3e   rel %6.3f%% %6.3f%%" % (n, sc, float((a - c32).abs().max()), float((b - c32).abs().max()),
+                                                               100 * float((a - c32).abs().max()) / sc, 100 * float((b - c32).abs().max()) / sc))

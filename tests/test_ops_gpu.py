@@ -1595,3 +1595,40 @@ def test_concat_group_equals_cat_of_group_point(hf, c, ch):
     assert torch.equal(out, ref)
     assert torch.equal(head.grad, h2.grad)
     assert torch.allclose(pts.grad, p2.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_group_point_gradient_in_gather_form(hf, oracle_mod):
+    """hf_index_inverse + hf_group_point_grad_gather: the gradient of the feature gather of an X-Conv written once per data point
+    over the CSR inverse of the neighbour table -- bit for bit the oracle's sequential accumulation (ascending (query, slot)
+    order), and equal to rounding to the atomic scatter it replaces; hubs (one point named by every query), unreferenced
+    points, a non-multiple-of-4 width"""
+    from heterofusionrcnn_amd.grouping import concat_group, index_inverse
+    rng = np.random.default_rng(12)
+    for (b, n, m, k, c, ch) in ((2, 300, 500, 8, 32, 16), (1, 4096, 16384, 8, 64, 64), (3, 70, 40, 4, 5, 3), (1, 16384, 4096, 8, 256, 64)):
+        idx = rng.integers(0, n, (b, m, k)).astype(np.int32)
+        idx[:, :, 0] = 7 % n                                    # a hub
+        idx[idx == (n - 1)] = 0                                 # point n-1 is never referenced
+        pts = dev(rng.standard_normal((b, n, c)).astype(np.float32)).requires_grad_(True)
+        head = dev(rng.standard_normal((b, m, k, ch)).astype(np.float32)).requires_grad_(True)
+        go = rng.standard_normal((b, m, k, ch + c)).astype(np.float32)
+        i_d = dev(idx)
+        off, ent = index_inverse(i_d, n)
+        # the inverse is a permutation of the flat positions, grouped by target, ascending inside a group
+        o, e = host(off), host(ent)
+        for bb in range(b):
+            assert o[bb, 0] == 0 and o[bb, -1] == m * k and np.array_equal(np.sort(e[bb]), np.arange(m * k))
+            flat = idx[bb].reshape(-1)
+            assert np.array_equal(flat[e[bb]], np.repeat(np.arange(n), np.diff(o[bb])))
+            starts = o[bb, :-1]
+            inner = np.ones(m * k, bool)
+            inner[starts[starts < m * k]] = False
+            assert (np.diff(e[bb])[inner[1:]] > 0).all()
+        out = concat_group(head, pts, i_d, (off, ent))
+        g_pts, g_head = torch.autograd.grad(out, (pts, head), dev(go))
+        want = oracle_mod.group_point_grad((b, n, c), idx, np.ascontiguousarray(go[..., ch:]))
+        assert np.array_equal(host(g_pts), want), (b, n, m, k, c)
+        assert np.array_equal(host(g_head), go[..., :ch])
+        out2 = concat_group(head, pts, i_d)
+        g2 = torch.autograd.grad(out2, pts, dev(go))[0]
+        np.testing.assert_allclose(host(g2), want, rtol=0, atol=2e-4 * max(1.0, np.abs(want).max()))
+        assert not host(g_pts)[:, n - 1].any()
