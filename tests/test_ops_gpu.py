@@ -944,24 +944,29 @@ def test_full_size_config2_stack_fwd_bwd_against_op_by_op_form(hf):
             up = x.reshape(b_, n_, -1)
         return up
 
-    g_out = dev(np.random.default_rng(6).standard_normal((8, 16384, model.out_channel)).astype(np.float32)) / 16384.0
+    # the loss: mean squared distance to a fixed per-channel target.  (A random cotangent makes every column sum of the
+    # backward pass a heavily cancelling sum in which ONE flipped ReLU mask -- either fp32 path flips a few against an fp64
+    # evaluation -- is a percent-level change; profiles/r03_grad_noise.md has both variants, per node and end to end.)
+    tgt = torch.linspace(-1.0, 1.0, model.out_channel, device="cuda")
+    lossf = lambda o: ((o - tgt) ** 2).mean()
     params = list(model.parameters())
     out = model(xyz, inten, geometry=model.geometry(xyz))
-    grads = torch.autograd.grad(out, params, g_out, allow_unused=True)
+    grads = torch.autograd.grad(lossf(out), params, allow_unused=True)
     ref = stack_ref(xyz, inten)
-    grads_ref = torch.autograd.grad(ref, params, g_out, allow_unused=True)
+    grads_ref = torch.autograd.grad(lossf(ref), params, allow_unused=True)
     torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3)
-    # Gradients of a BatchNorm stack over 10^5..10^6 rows carry fp32 noise of their own: against an fp64 evaluation of
-    # the same graph the op-by-op fp32 form is off by up to 0.35 % of a parameter's largest component, the fused path by up
-    # to 2 % (scripts/probes/grad_noise_probe.py).  Bound: 3 % of the largest component of each parameter's gradient.
+    # Measured against an fp64 evaluation of the same graph (scripts/probes/grad_noise_probe.py, LOSS=smooth): the op-by-op fp32
+    # form is within 0.19 % of a parameter's largest gradient component, the fused path within 0.61 % (one parameter; the rest
+    # within 0.31 %); node by node the HIP passes are as accurate as the framework's (scripts/probes/bn_layer_noise.py,
+    # pool_node_noise.py).  Bound between the two fp32 paths: 1 % of the largest component (round 2: 3 %).
     for (name, _), a, b in zip(model.named_parameters(), grads, grads_ref):
         if a is None or b is None or name.endswith("fc.bias"):
             # a bias in front of a BatchNorm has an exactly-zero gradient analytically: the fused node returns zeros,
             # autograd through the op-by-op form returns rounding noise
             assert (a is None or float(a.abs().max()) < 1e-3) and (b is None or float(b.abs().max()) < 1e-3), name
             continue
-        scale = float(b.abs().max()) + 1e-7
-        assert float((a - b).abs().max()) <= 3e-2 * scale + 1e-6, (name, float((a - b).abs().max()), scale)
+        scale = float(b.abs().max()) + 1e-9
+        assert float((a - b).abs().max()) <= 1e-2 * scale + 1e-8, (name, float((a - b).abs().max()), scale)
 
 
 def test_iou3d_and_nms_adapters(hf, oracle_mod):
