@@ -83,6 +83,9 @@ _SIGNATURES = {
     "hf_project_gather_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_fuse_concat": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_fuse_concat_grad": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "hf_rpn_loss_workspace": [],
+    "hf_rpn_loss_fwd": [ctypes.c_longlong, _i, _i, _i] + [_vp] * 11 + [_f, _f, _f, _vp, _vp, _sz, _vp],
+    "hf_rpn_loss_bwd": [ctypes.c_longlong, _i, _i, _i] + [_vp] * 11 + [_f, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "hf_bin_box_decode": [ctypes.c_longlong, _i] + [_vp] * 13 + [_f, _f, _vp, _vp],
     "hf_bin_box_encode": [ctypes.c_longlong, _i, _i] + [_vp] * 7 + [_f, _f, _f, _f] + [_vp] * 8 + [_vp],
     "hf_bin_head_decode": [ctypes.c_longlong, _i, _i, _i, _i] + [_vp] * 6 + [_f, _f, _vp, _vp, _vp],
@@ -101,6 +104,7 @@ _SIGNATURES = {
 _RESTYPES = {
     "hf_fps_workspace": _sz,
     "hf_ball_query_workspace": _sz,
+    "hf_rpn_loss_workspace": _sz,
     "hf_oriented_nms_workspace": _sz,
     "hf_bn_workspace": _sz,
     "hf_three_nn_workspace": _sz,

@@ -253,6 +253,158 @@ __global__ void fuse_concat_grad_kernel(long long rows, int c1, int c2, const fl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The RPN loss (rpn_model.py:1040-1128 + hf/core/losses.py:131-226) in two passes instead of ~80 framework kernels:
+//   segmentation   focal loss on the softmax of the K+1 logits: alpha (1 - p_t)^2 (-log p_t), p_t clipped to [1e-7, 1 - 1e-7],
+//                  summed over all points, x seg_weight / rows;
+//   foreground points (label > 0), on the head row of the labelled class: softmax cross-entropy of the x / z / theta bin
+//                  logits (x cls_weight) and smooth-L1 of the residual of the TRUE bin for x / z / theta, of y and of the three
+//                  sizes (x reg_weight), both / max(number of foreground points, 1).
+// Targets come straight from hf_bin_box_encode (per class for x / z): the kernel picks the labelled class's entries
+// (the per-class gathers of rpn_model.py:733-776).  Forward: per-block partial sums (seg, cls, reg, #fg).  Backward: gradients
+// w.r.t. the segmentation logits and the head, scaled by the upstream gradient read from the device; grad_head is zero-filled by
+// the caller's memset and only foreground rows are written.
+// ------------------------------------------------------------------------------------------
+constexpr int kLossMaxK1 = 8, kLossMaxBins = 32;
+struct LossArgs {
+    long long rows;
+    int k, nbx, nbt;   // classes, x/z bins, theta bins; head row = [bx nbx | rx nbx | bz nbx | rz nbx | bt nbt | rt nbt | ry | size 3]
+    const float *seg_logits, *head;
+    const int *label;                       // 0 = background, 1..k
+    const int *bin_x, *bin_z, *bin_t;       // (rows, k), (rows, k), (rows)
+    const float *res_x, *res_z, *res_t, *res_y, *res_size;   // (rows, k), (rows, k), (rows), (rows), (rows, 3)
+    float seg_w, cls_w, reg_w;
+};
+
+__device__ __forceinline__ float smooth_l1(float d) { const float a = fabsf(d); return a < 1.0f ? 0.5f * a * a : a - 0.5f; }
+__device__ __forceinline__ float smooth_l1_grad(float d) { return fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void rpn_loss_kernel(LossArgs a, float *__restrict__ partial, const float *__restrict__ nfg_total,
+                                                      const float *__restrict__ upstream, float *__restrict__ grad_seg,
+                                                      float *__restrict__ grad_head)
+{
+    __shared__ float red[4][256];
+    const int d = 4 * a.nbx + 2 * a.nbt + 4;
+    const int k1 = a.k + 1;
+    float s_seg = 0.f, s_cls = 0.f, s_reg = 0.f, s_fg = 0.f;
+    float gscale = 0.f, inv_den = 0.f;
+    if (BWD) {
+        gscale = upstream[0];
+        inv_den = 1.0f / fmaxf(nfg_total[0], 1.0f);
+    }
+    const float seg_scale = a.seg_w / static_cast<float>(a.rows);
+    for (long long r = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; r < a.rows;
+         r += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const int lab = a.label[r];
+        // ---- segmentation: softmax over k1 logits, focal term of the true class
+        float lg[kLossMaxK1], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kLossMaxK1; ++j) { lg[j] = j < k1 ? a.seg_logits[r * k1 + j] : -INFINITY; mx = fmaxf(mx, lg[j]); }
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < kLossMaxK1; ++j) { lg[j] = j < k1 ? expf(lg[j] - mx) : 0.f; se += lg[j]; }
+        const float inv = 1.0f / se;
+        float pt_raw = 0.f;
+#pragma unroll
+        for (int j = 0; j < kLossMaxK1; ++j) { lg[j] *= inv; if (j == lab) pt_raw = lg[j]; }
+        const float pt = fminf(fmaxf(pt_raw, 1e-7f), 1.0f - 1e-7f);
+        const float om = 1.0f - pt;
+        if (!BWD) {
+            s_seg += 0.25f * om * om * (-logf(pt));
+        } else {
+            // d/dpt [alpha (1-pt)^2 (-log pt)] = alpha (2 (1-pt) log pt - (1-pt)^2 / pt); zero where the clip is active
+            const float inside = (pt_raw >= 1e-7f && pt_raw <= 1.0f - 1e-7f) ? 1.0f : 0.0f;
+            const float dpt = inside * 0.25f * (2.0f * om * logf(pt) - om * om / pt) * seg_scale * gscale;
+#pragma unroll
+            for (int j = 0; j < kLossMaxK1; ++j)
+                if (j < k1) grad_seg[r * k1 + j] = dpt * pt_raw * ((j == lab ? 1.0f : 0.0f) - lg[j]);
+        }
+        if (lab <= 0) continue;
+        // ---- the labelled class's row of the head
+        const int c = lab - 1;
+        const float *h = a.head + (r * a.k + c) * d;
+        float *gh = BWD ? grad_head + (r * a.k + c) * d : nullptr;
+        s_fg += 1.0f;
+        const int tb[3] = { a.bin_x[r * a.k + c], a.bin_z[r * a.k + c], a.bin_t[r] };
+        const float tr[3] = { a.res_x[r * a.k + c], a.res_z[r * a.k + c], a.res_t[r] };
+        int off = 0;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int nb = g < 2 ? a.nbx : a.nbt;
+            float v[kLossMaxBins], m2 = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < kLossMaxBins; ++j) { v[j] = j < nb ? h[off + j] : -INFINITY; m2 = fmaxf(m2, v[j]); }
+            float s2 = 0.f, vt = 0.f;
+#pragma unroll
+            for (int j = 0; j < kLossMaxBins; ++j) { if (j == tb[g]) vt = v[j]; v[j] = j < nb ? expf(v[j] - m2) : 0.f; s2 += v[j]; }
+            const float res = h[off + nb + tb[g]];          // the residual of the TRUE bin (rpn_model.py:778-786)
+            if (!BWD) {
+                s_cls += logf(s2) + m2 - vt;
+                s_reg += smooth_l1(res - tr[g]);
+            } else {
+                const float cs = a.cls_w * inv_den * gscale, is2 = 1.0f / s2;
+#pragma unroll
+                for (int j = 0; j < kLossMaxBins; ++j)
+                    if (j < nb) gh[off + j] = cs * (v[j] * is2 - (j == tb[g] ? 1.0f : 0.0f));
+                for (int j = 0; j < nb; ++j) gh[off + nb + j] = 0.0f;
+                gh[off + nb + tb[g]] = a.reg_w * inv_den * gscale * smooth_l1_grad(res - tr[g]);
+            }
+            off += 2 * nb;
+        }
+        const float dy = h[off] - a.res_y[r];
+        if (!BWD) s_reg += smooth_l1(dy); else gh[off] = a.reg_w * inv_den * gscale * smooth_l1_grad(dy);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float ds = h[off + 1 + j] - a.res_size[r * 3 + j];
+            if (!BWD) s_reg += smooth_l1(ds); else gh[off + 1 + j] = a.reg_w * inv_den * gscale * smooth_l1_grad(ds);
+        }
+    }
+    if (BWD) return;
+    const int t = threadIdx.x;
+    red[0][t] = s_seg; red[1][t] = s_cls; red[2][t] = s_reg; red[3][t] = s_fg;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][t] += red[q][t + w];
+        }
+        __syncthreads();
+    }
+    if (t < 4) partial[blockIdx.x * 4 + t] = red[t][0];
+}
+
+// one workgroup: the four column sums of the partials in fp64 -> out[0..3] = (seg, cls, reg, #fg) raw sums, out[4] = the loss
+__global__ __launch_bounds__(256) void rpn_loss_finalize_kernel(int nblk, long long rows, float seg_w, float cls_w, float reg_w,
+                                                               const float *__restrict__ partial, float *__restrict__ out)
+{
+    __shared__ double red[4][256];
+    const int t = threadIdx.x;
+    double s[4] = { 0.0, 0.0, 0.0, 0.0 };
+    for (int i = t; i < nblk; i += 256)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] += static_cast<double>(partial[i * 4 + q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[q][t] = s[q];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][t] += red[q][t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double den = red[3][0] > 1.0 ? red[3][0] : 1.0;
+        const double seg = red[0][0] * seg_w / static_cast<double>(rows), cls = red[1][0] * cls_w / den, reg = red[2][0] * reg_w / den;
+        out[0] = static_cast<float>(seg); out[1] = static_cast<float>(cls); out[2] = static_cast<float>(reg);
+        out[3] = static_cast<float>(red[3][0]); out[4] = static_cast<float>(seg + cls + reg);
+    }
+}
+
+constexpr int kLossBlocks = 1024;
+
 static int glue_grid(long long items, int block)
 {
     long long g = (items + block - 1) / block;
@@ -329,6 +481,55 @@ HF_API int hf_fuse_concat_grad(long long rows, int c1, int c2, const float *grad
     else
         hipLaunchKernelGGL((fuse_concat_grad_kernel<1>), dim3(glue_grid(rows * (c1 + c2), 256)), dim3(256), 0, as_stream(stream),
                            rows, c1, c2, grad_out, masks, grad_a, grad_b);
+    return launch_status();
+}
+
+static int loss_args_ok(long long rows, int k, int nbx, int nbt, const void *a, const void *b, const void *c)
+{
+    return rows >= 0 && k > 0 && k + 1 <= kLossMaxK1 && nbx > 0 && nbx <= kLossMaxBins && nbt > 0 && nbt <= kLossMaxBins && (rows == 0 || (a && b && c));
+}
+
+HF_API size_t hf_rpn_loss_workspace(void) { return sizeof(float) * 4 * kLossBlocks; }
+
+HF_API int hf_rpn_loss_fwd(long long rows, int k, int nbx, int nbt, const float *seg_logits, const float *head, const int *label,
+                           const int *bin_x, const float *res_x, const int *bin_z, const float *res_z, const int *bin_theta,
+                           const float *res_theta, const float *res_y, const float *res_size, float seg_weight, float cls_weight,
+                           float reg_weight, float *out5, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (!loss_args_ok(rows, k, nbx, nbt, seg_logits, head, label) || !out5) return HF_EINVAL;
+    if (rows > 0 && (!bin_x || !res_x || !bin_z || !res_z || !bin_theta || !res_theta || !res_y || !res_size)) return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_rpn_loss_workspace()) return HF_EWORKSPACE;
+    LossArgs a = { rows, k, nbx, nbt, seg_logits, head, label, bin_x, bin_z, bin_theta, res_x, res_z, res_theta, res_y, res_size,
+                   seg_weight, cls_weight, reg_weight };
+    int nblk = static_cast<int>((rows + 255) / 256);
+    if (nblk > kLossBlocks) nblk = kLossBlocks;
+    if (nblk < 1) nblk = 1;
+    float *partial = static_cast<float *>(workspace);
+    hipLaunchKernelGGL((rpn_loss_kernel<false>), dim3(nblk), dim3(256), 0, as_stream(stream), a, partial, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(rpn_loss_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), nblk, rows > 0 ? rows : 1, seg_weight, cls_weight,
+                       reg_weight, partial, out5);
+    return launch_status();
+}
+
+HF_API int hf_rpn_loss_bwd(long long rows, int k, int nbx, int nbt, const float *seg_logits, const float *head, const int *label,
+                           const int *bin_x, const float *res_x, const int *bin_z, const float *res_z, const int *bin_theta,
+                           const float *res_theta, const float *res_y, const float *res_size, float seg_weight, float cls_weight,
+                           float reg_weight, const float *out5, const float *upstream, float *grad_seg, float *grad_head,
+                           hf_stream_t stream)
+{
+    if (!loss_args_ok(rows, k, nbx, nbt, seg_logits, head, label) || !out5 || !upstream || (rows > 0 && (!grad_seg || !grad_head)))
+        return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    if (!bin_x || !res_x || !bin_z || !res_z || !bin_theta || !res_theta || !res_y || !res_size) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int d = 4 * nbx + 2 * nbt + 4;
+    int rc = hip_status(hipMemsetAsync(grad_head, 0, sizeof(float) * static_cast<size_t>(rows) * k * d, st));
+    if (rc != HF_OK) return rc;
+    LossArgs a = { rows, k, nbx, nbt, seg_logits, head, label, bin_x, bin_z, bin_theta, res_x, res_z, res_theta, res_y, res_size,
+                   seg_weight, cls_weight, reg_weight };
+    int nblk = static_cast<int>((rows + 255) / 256);
+    if (nblk > kLossBlocks * 4) nblk = kLossBlocks * 4;
+    hipLaunchKernelGGL((rpn_loss_kernel<true>), dim3(nblk), dim3(256), 0, st, a, nullptr, out5 + 3, upstream, grad_seg, grad_head);
     return launch_status();
 }
 

@@ -455,9 +455,10 @@ static int launch_ball_query_bruteforce(int b, int n, int m, float thresh, int n
 }
 
 // variant: HF_BQ_AUTO picks by shape; the others force one kernel (tests cover every path this way).
-//   auto: with a workspace and at least four rounds of the single-launch kernel's workgroups (the batched launches of a train
-//         step: 32 clouds of 4096 queries and up) -> the cell-sorted pair of kernels (ballquery_sorted.hip: the cell structure
-//         is built once per cloud; measured 52 us against 70 us at 80 clouds, equal at 32, 23 against 16 at 16 clouds);
+//   auto: with a workspace, 32 clouds and up, and more than one round of the single-launch kernel's workgroups (the batched
+//         launches of a train step) -> the cell-sorted pair of kernels (ballquery_sorted.hip: the cell structure is built once
+//         per cloud; measured at 80 clouds 52-57 us against 70 us (16384 points, r 0.5), 20 against 31 us (4096 points),
+//         18 against 20 us (1024 points); equal at 32 clouds; 23 against 16 us at 16 clouds);
 //         else the single-launch cell kernel (ballquery.hip); shapes outside both ranges (nsample > 128, n > 2^19 points per
 //         cloud, infinite radius) take the brute-force kernel.
 static int launch_ball_query(int variant, int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
@@ -469,7 +470,7 @@ static int launch_ball_query(int variant, int b, int n, int m, float radius, int
     if (variant == HF_BQ_SORTED)
         return launch_ball_query_sorted(b, n, m, radius, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, workspace,
                                         workspace_bytes, st);
-    if (variant == HF_BQ_AUTO && workspace && static_cast<long long>(b) * div_up(m, 128) >= 4LL * kNumCU) {
+    if (variant == HF_BQ_AUTO && workspace && b >= 32 && static_cast<long long>(b) * div_up(m, 128) > kNumCU) {
         const int rc = launch_ball_query_sorted(b, n, m, radius, thresh, nsample, xyz1, xyz2, center, idx, pts_cnt, grouped, workspace,
                                                 workspace_bytes, st);
         if (rc != HF_EINVAL) return rc;

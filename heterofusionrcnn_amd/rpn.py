@@ -373,6 +373,57 @@ def rpn_loss(cfg: RpnConfig, seg_logits, head, label_cls, targets):
                              "num_foreground": nfg.detach()}
 
 
+class _RpnLossFused(torch.autograd.Function):
+    """hf_rpn_loss_fwd / hf_rpn_loss_bwd: targets picked for the labelled class, focal + cross-entropy + smooth-L1 terms and
+    their gradients in two passes over the head (the op-by-op form above is ~80 framework kernels and a dozen passes).
+    Returns [segmentation, bin classification, regression, #foreground, total]; only the total carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, seg_logits, head, label, enc, k, nbx, nbt, weights):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+        L = _lib.lib()
+        rows = label.numel()
+        out5 = torch.empty((5,), dtype=torch.float32, device=head.device)
+        nbytes = L.hf_rpn_loss_workspace()
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=head.device)
+        seg_logits, head = seg_logits.contiguous(), head.contiguous()
+        args = [ptr(t) for t in (seg_logits, head, label) + tuple(enc)]
+        check(L.hf_rpn_loss_fwd(rows, k, nbx, nbt, *args, weights[0], weights[1], weights[2], ptr(out5), ptr(ws), nbytes, stream_ptr()),
+              "rpn_loss_fwd")
+        ctx.save_for_backward(seg_logits, head, label, out5, *enc)
+        ctx.meta = (rows, k, nbx, nbt, weights)
+        return out5
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+        seg_logits, head, label, out5 = ctx.saved_tensors[:4]
+        enc = ctx.saved_tensors[4:]
+        rows, k, nbx, nbt, weights = ctx.meta
+        up = g[4:5].contiguous()
+        grad_seg, grad_head = torch.empty_like(seg_logits), torch.empty_like(head)
+        args = [ptr(t) for t in (seg_logits, head, label) + tuple(enc)]
+        check(_lib.lib().hf_rpn_loss_bwd(rows, k, nbx, nbt, *args, weights[0], weights[1], weights[2], ptr(out5), ptr(up), ptr(grad_seg),
+                                         ptr(grad_head), stream_ptr()), "rpn_loss_bwd")
+        return grad_seg, grad_head, None, None, None, None, None, None
+
+
+def rpn_loss_fused(cfg: RpnConfig, xyz, seg_logits, head, label_cls, label_reg):
+    """the same loss as rpn_targets + rpn_loss through the two HIP passes; -> (loss, parts)"""
+    k = cfg.num_classes
+    lab = label_cls.to(torch.int32).contiguous()
+    cls0 = torch.clamp(label_cls.long() - 1, min=0)
+    mean_sizes = box_codec.const_f32(xyz.device, cfg.cluster_sizes)[cls0]
+    enc = box_codec.encode(xyz, 0, label_reg, mean_sizes, cfg.xz_search_range, cfg.xz_bin_len, cfg.r_theta, cfg.delta_theta, k)
+    bin_x, res_x, bin_z, res_z, bin_t, res_t, res_y, res_size = enc
+    out5 = _RpnLossFused.apply(seg_logits, head, lab, (bin_x, res_x, bin_z, res_z, bin_t, res_t, res_y, res_size), k, cfg.num_bin_xz,
+                               cfg.theta_bin_num, (float(cfg.seg_loss_weight), float(cfg.cls_loss_weight), float(cfg.reg_loss_weight)))
+    d = out5.detach()
+    return out5[4], {"segmentation": d[0], "bin_classification": d[1], "regression": d[2], "num_foreground": d[3]}
+
+
 # ------------------------------------------------------------------------------------------------ model
 class RpnModel(nn.Module):
     def __init__(self, cfg: RpnConfig):
@@ -424,7 +475,13 @@ class RpnModel(nn.Module):
                 "num_before_padding": torch.clamp(num, max=post_nms_size), "rpn_fts": fused, "fg_mask": fg_mask, "point_scores": scores,
                 "pre_nms_boxes": top_b, "pre_nms_scores": top_s, "keep": keep, "num_kept": num}
 
-    def loss(self, xyz, seg_logits, head, label_cls, label_reg):
+    def loss(self, xyz, seg_logits, head, label_cls, label_reg, fused=None):
+        """fused (default: on the device in fp32): the two-pass HIP loss; else the op-by-op torch form it is tested against"""
+        if fused is None:
+            fused = head.is_cuda and head.dtype == torch.float32 and self.cfg.num_classes + 1 <= 8 and self.cfg.num_bin_xz <= 32 \
+                and self.cfg.theta_bin_num <= 32
+        if fused:
+            return rpn_loss_fused(self.cfg, xyz, seg_logits, head, label_cls, label_reg)
         with torch.no_grad():
             targets = rpn_targets(self.cfg, xyz, label_cls, label_reg)
         return rpn_loss(self.cfg, seg_logits, head, label_cls, targets)

@@ -379,6 +379,25 @@ int hf_fuse_concat(long long rows, int c1, int c2, const float *a, const float *
                    hf_stream_t stream);
 int hf_fuse_concat_grad(long long rows, int c1, int c2, const float *grad_out, const float *masks, float *grad_a,
                         float *grad_b, hf_stream_t stream);
+/* The RPN loss (hf/core/models/rpn_model.py:1040-1128 with hf/core/losses.py:131-226) in two passes.  rows = B*P points;
+ * seg_logits (rows, k+1); head (rows, k, D), D = 4 nbx + 2 nbt + 4 laid out as _parse_rpn_output slices it (:870-935);
+ * label (rows) int32: 0 background, 1..k; the targets exactly as hf_bin_box_encode writes them (bin_x / res_x / bin_z / res_z
+ * (rows, k), bin_theta / res_theta / res_y (rows), res_size (rows, 3)): the labelled class's entries are picked here
+ * (:733-776).  hf_rpn_loss_fwd -> out5 = [segmentation, bin classification, regression, #foreground, total loss]
+ * (focal alpha 0.25 gamma 2 on the clipped softmax, x seg_weight / rows; softmax cross-entropy of the three bin groups and
+ * smooth-L1 of the true bin's residuals, y and the sizes over foreground points, / max(#fg, 1)).  hf_rpn_loss_bwd -> the
+ * gradients w.r.t. seg_logits and head times *upstream (a device scalar); grad_head is zero-filled here.
+ * workspace: hf_rpn_loss_workspace() bytes. */
+size_t hf_rpn_loss_workspace(void);
+int hf_rpn_loss_fwd(long long rows, int k, int nbx, int nbt, const float *seg_logits, const float *head, const int *label,
+                    const int *bin_x, const float *res_x, const int *bin_z, const float *res_z, const int *bin_theta,
+                    const float *res_theta, const float *res_y, const float *res_size, float seg_weight, float cls_weight,
+                    float reg_weight, float *out5, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+int hf_rpn_loss_bwd(long long rows, int k, int nbx, int nbt, const float *seg_logits, const float *head, const int *label,
+                    const int *bin_x, const float *res_x, const int *bin_z, const float *res_z, const int *bin_theta,
+                    const float *res_theta, const float *res_y, const float *res_size, float seg_weight, float cls_weight,
+                    float reg_weight, const float *out5, const float *upstream, float *grad_seg, float *grad_head,
+                    hf_stream_t stream);
 /* hf/core/bin_based_box3d_encoder.py:9-139 (tf_decode) for `rows` reference points x k classes: rows = B*p in the RPN
  * (ref_theta NULL = the constant 0), the RoI count in the RCNN.  Per (row, class) inputs are (rows, k[, 3]) arrays;
  * ss / deltas (k,) the per-class XZ search range and bin length; boxes (rows, k, 7) = [x, y, z, l, w, h, ry]. */

@@ -262,3 +262,34 @@ def test_rpn_backbone_fused_nodes_equal_op_by_op_torch_form():
             continue
         scale = float(b.abs().max()) + 1e-6
         assert float((a - b).abs().max()) <= 2e-2 * scale + 1e-5, (n, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 3])
+def test_fused_rpn_loss_against_the_op_by_op_form(k):
+    """hf_rpn_loss_fwd / _bwd against rpn_targets + rpn_loss (which the CPU tests pin to the literal reference graph): the
+    loss, its three parts, the foreground count, and the gradients w.r.t. the segmentation logits and the head -- also with an
+    upstream factor, with clipped softmax probabilities (|logit| = 40), and with no foreground point at all"""
+    cfg = _small_cfg() if k == 3 else R_.rpn_stack_config2()
+    xyz, _, label_cls, label_reg = _small_batch(cfg, "cuda", b=2, p=4096, seed=9)
+    assert int((label_cls > 0).sum()) > 50
+    g = torch.Generator().manual_seed(5)
+    for case in ("plain", "upstream", "clipped", "no_foreground"):
+        lab = torch.zeros_like(label_cls) if case == "no_foreground" else label_cls
+        seg = torch.randn(2, 4096, cfg.num_classes + 1, generator=g).cuda()
+        if case == "clipped":
+            seg = seg * 40.0
+        seg.requires_grad_(True)
+        head = (2 * torch.randn(2, 4096, cfg.num_classes, cfg.head_width, generator=g)).cuda().requires_grad_(True)
+        model = R_.RpnModel(cfg)                      # only its .loss is used: no device weights needed
+        up = 0.37 if case == "upstream" else 1.0
+        loss_f, parts_f = model.loss(xyz, seg, head, lab, label_reg, fused=True)
+        gf = torch.autograd.grad(loss_f * up, (seg, head))
+        loss_r, parts_r = model.loss(xyz, seg, head, lab, label_reg, fused=False)
+        gr = torch.autograd.grad(loss_r * up, (seg, head), allow_unused=True)
+        assert torch.allclose(loss_f, loss_r, rtol=2e-5, atol=1e-6), (case, float(loss_f), float(loss_r))
+        for name in ("segmentation", "bin_classification", "regression", "num_foreground"):
+            assert torch.allclose(parts_f[name].float(), parts_r[name].float(), rtol=2e-5, atol=1e-6), (case, name)
+        for a, b in zip(gf, gr):
+            b = torch.zeros_like(a) if b is None else b
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 + 1e-5 * float(b.abs().max())), (case, float((a - b).abs().max()))
