@@ -437,7 +437,7 @@ class PointCnnBackbone(nn.Module):
             dec_idx = [self.dec[li].neighbours(pts[pi + 1], pts[qi + 1]) for li, (k, d, pi, qi) in enumerate(self.cfg.xdconv)]
             # the inverse of every neighbour table (for each data point the (query, slot) pairs that name it): the gradient of
             # the feature gather then writes every row once instead of scattering atomics
-            inv = lambda idx, n: index_inverse(idx, n) if n <= INVERSE_MAX_TARGETS else None
+            inv = lambda idx, n: index_inverse(idx, n) if (self.training and n <= INVERSE_MAX_TARGETS) else None   # a backward pass only
             enc_inv = [inv(ix, pts[li].shape[1]) for li, ix in enumerate(enc_idx)]
             dec_inv = [inv(ix, pts[pi + 1].shape[1]) for ix, (k, d, pi, qi) in zip(dec_idx, self.cfg.xdconv)]
         return {"pts": pts, "enc": enc_idx, "dec": dec_idx, "enc_inv": enc_inv, "dec_inv": dec_inv}
