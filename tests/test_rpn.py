@@ -293,3 +293,51 @@ def test_fused_rpn_loss_against_the_op_by_op_form(k):
         for a, b in zip(gf, gr):
             b = torch.zeros_like(a) if b is None else b
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 + 1e-5 * float(b.abs().max())), (case, float((a - b).abs().max()))
+
+
+@pytest.mark.gpu
+def test_full_size_pointnet_rpn_step_b8_properties():
+    """hf/configs/rpn_cars_pointnet_paper.config at its own sizes, 8 frames of 16384 points (round 2's bench workload): the
+    prefetched geometry gives bit-identical outputs to the inline geometry, the fused loss equals the op-by-op loss, every
+    gradient is finite and non-trivial, three Adam steps reduce the loss"""
+    import bench
+    from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
+    cfg = R_.rpn_cars_pointnet_paper()
+    rng = np.random.default_rng(21)
+    xyz = torch.from_numpy(bench.kitti_uniform(rng, 8, bench.N0)).cuda()
+    inten = torch.from_numpy(rng.uniform(-0.5, 0.5, (8, bench.N0, 1)).astype(np.float32)).cuda()
+    gt_boxes, gt_cls = R_.synthetic_ground_truth(rng, 8, 12, cfg, ground_y=3.0)
+    label_cls, label_reg = R_.point_labels(xyz, torch.from_numpy(gt_boxes).cuda(), torch.from_numpy(gt_cls).cuda())
+    assert int((label_cls > 0).sum()) > 100
+    torch.manual_seed(2)
+    model = R_.RpnModel(cfg).cuda().train()
+    model.backbone.fc_keep = [1.0] * len(model.backbone.fc_keep)          # dropout off: two evaluations must agree bit for bit
+    model.heads.drop = [0.0] * len(model.heads.drop)
+    pf = GeometryPrefetcher(model.geometry, depth=1, group=1)
+    pf.submit(xyz)
+    geo = pf.get()
+    with torch.no_grad():
+        seg_a, head_a = model(xyz, inten)
+        for m in model.modules():                                         # the first pass moved the running statistics only
+            pass
+        seg_b, head_b = model(xyz, inten, geometry=geo)
+    assert seg_a.shape == (8, bench.N0, 2) and head_a.shape == (8, bench.N0, 1, 76)
+    assert torch.equal(seg_a, seg_b) and torch.equal(head_a, head_b)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    losses = []
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        seg, head = model(xyz, inten, geometry=geo)
+        loss, parts = model.loss(xyz, seg, head, label_cls, label_reg)
+        if it == 0:
+            loss_ref, _ = model.loss(xyz, seg, head, label_cls, label_reg, fused=False)
+            assert torch.allclose(loss, loss_ref, rtol=2e-5, atol=1e-6)
+            assert float(parts["num_foreground"]) == float((label_cls > 0).sum())
+        loss.backward()
+        if it == 0:
+            for n, p_ in model.named_parameters():
+                assert p_.grad is not None and torch.isfinite(p_.grad).all(), n
+            assert sum(float(p_.grad.abs().sum()) > 0 for p_ in model.parameters()) > 100
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
