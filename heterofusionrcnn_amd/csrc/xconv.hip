@@ -464,6 +464,10 @@ HF_API int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float 
         const size_t lds = c <= kXcThreads / 2 ? sizeof(float) * static_cast<size_t>(k) * m * c : 0;   // block-level reduction when a block holds >= 2 row slots
         if (lds > 48 * 1024) return HF_EINVAL;
         long long chunks = (2 * kNumCU + cblocks - 1) / cblocks;
+        // every chunk ends in one atomic per coefficient on the SAME k*c*m addresses: with few rows (one frame per GPU) 512
+        // chunks were 40 us of serialised atomics for 5 us of work; at least 64 rows per chunk
+        if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
+        if (chunks < 1) chunks = 1;
         if (chunks > rows) chunks = rows;
         if (chunks > 65535) chunks = 65535;
         const int rows_per_chunk = static_cast<int>((rows + chunks - 1) / chunks);

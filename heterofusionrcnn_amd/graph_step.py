@@ -8,9 +8,11 @@ frame per GPU (BASELINE config 4: a batch of 8 over 8 GPUs).  Here the step is c
   static slots     the frames (xyz, intensity, image feature map, calibration, labels) and the coordinate-only geometry
                    (sampled points, neighbour tables: pipeline.GeometryPrefetcher computes it ahead on side streams) live in
                    fixed buffers; a step copies its inputs in (one foreach copy) and replays the graph;
-  flat gradients   every parameter's .grad is a view into ONE buffer, zeroed inside the graph: with several ranks the
-                   gradient exchange is one RCCL all-reduce of that buffer (hvd.DistributedOptimizer averages gradients,
-                   trainer.py:71), followed by the fused Adam step; with one rank Adam is part of the graph;
+  flat gradients   with several ranks the gradients are gathered into ONE buffer by a foreach copy at the end of the captured
+                   backward pass; the exchange is one RCCL all-reduce of that buffer (hvd.DistributedOptimizer averages
+                   gradients, trainer.py:71), followed by the fused Adam step on views of it; with one rank Adam is part of
+                   the graph and reads the gradients where autograd left them.  (Pre-set .grad views would make autograd ADD
+                   every gradient into the buffer: 250 extra kernels per step for this model.)
   random numbers   dropout and the path-drop coin flips draw from the device generator, whose Philox offset PyTorch
                    advances per replay: every step sees fresh masks, as in eager mode (tests/test_graph_step.py).
 
@@ -45,20 +47,40 @@ def tree_map(obj, fn):
 
 
 class FlatGrads:
-    """.grad of every parameter as a view into one contiguous buffer (gradient_as_bucket_view with a single bucket)"""
+    """One contiguous buffer with a view per parameter (gradient_as_bucket_view with a single bucket).  `adopt()` makes the views
+    the parameters' .grad (eager steps: autograd then accumulates into the zeroed buffer); `gather(grads)` copies freshly
+    produced gradients in with one foreach copy (captured steps)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         p0 = self.params[0]
         self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
-        o = 0
+        self.views, o = [], 0
         for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
+
+    def adopt(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def release(self):
+        for p in self.params:
+            p.grad = None
 
     def zero(self):
         self.flat.zero_()
+
+    def gather(self, grads):
+        """grads: one tensor (or None = zero gradient) per parameter"""
+        dst = [v for v, g in zip(self.views, grads) if g is not None]
+        src = [g for g in grads if g is not None]
+        for v, g in zip(self.views, grads):
+            if g is None:
+                v.zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def all_reduce_mean(self, world):
         """hvd.DistributedOptimizer: the average over the replicas, one collective for the whole model"""
@@ -90,6 +112,7 @@ class TrainStep:
         self.model, self.opt, self.world = model, optimizer, world
         self.loss_fn = loss_fn or _rpn_loss
         self.grads = FlatGrads(model.parameters())
+        self.flat_mode = world > 1                 # one rank: the optimizer reads the gradients where autograd leaves them
         self.inputs = dict(inputs)
         self.geometry = tree_map(geometry, lambda t: t.clone())       # static slots
         self._geo_slots = tree_tensors(self.geometry)
@@ -101,16 +124,22 @@ class TrainStep:
 
     # ------------------------------------------------------------------ pieces
     def _forward_backward(self):
-        self.grads.zero()
+        # fresh gradients every step (.grad = None: autograd assigns, it does not add); with several ranks they are gathered
+        # into the flat buffer by one foreach copy
+        self.grads.release()
         img = self.inputs.get("img_fts")
         if img is not None and img.requires_grad:
             img.grad = None                                           # a leaf outside the model: backward stores, never adds
         loss = self.loss_fn(self.model, self.inputs, self.geometry)
         loss.backward()
+        if self.flat_mode:
+            self.grads.gather([p.grad for p in self.grads.params])
         return loss.detach()
 
     def _finish(self):
-        self.grads.all_reduce_mean(self.world)
+        if self.flat_mode:
+            self.grads.all_reduce_mean(self.world)
+            self.grads.adopt()                                        # the optimizer steps on the averaged views
         self.opt.step()
 
     def _capture(self, warmup):
@@ -129,6 +158,10 @@ class TrainStep:
             self.loss = self._forward_backward()
             if self.opt_in_graph:
                 self.opt.step()
+        # the captured backward writes its gradients into the graph's own pool at every replay, whatever .grad points to
+        # afterwards: with several ranks the parameters adopt the flat views (filled by the captured foreach copy)
+        if self.flat_mode:
+            self.grads.adopt()
 
     # ------------------------------------------------------------------ a step
     def load(self, geometry=None, **inputs):
@@ -154,7 +187,8 @@ class TrainStep:
         else:
             self.graph.replay()
             if not self.opt_in_graph:
-                self._finish()
+                self.grads.all_reduce_mean(self.world)
+                self.opt.step()
         return self.loss
 
 

@@ -59,7 +59,9 @@ def _splitk_wgrad(g, x, chunk=None):
     230 us, 64 chunks of 1024 rows 46 us."""
     r = x.shape[0]
     if chunk is None:
-        chunk = 4096 if r >= 131072 else 1024
+        # ~256 chunks: 4096 rows each at a million rows (8 frames), 256 at 65 536 (one frame) -- 32 chunks of 4096 left the
+        # one-frame step with 32 workgroups per weight gradient (111 us each, profiles/r03_bench_1frame_graph_kernel_stats.csv)
+        chunk = 4096 if r >= (1 << 20) else (1024 if r >= (1 << 18) else (512 if r >= (1 << 17) else 256))
     if r < 32 * chunk or g.shape[1] * x.shape[1] > 512 * 512:
         # too few rows for a batched split: the MFMA kernel cuts them into chunks itself (8192 rows, 256x256: 30 us
         # against 53 us for the plain library GEMM)

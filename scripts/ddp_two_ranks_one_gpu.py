@@ -5,7 +5,9 @@ must hold identical weights.  RCCL itself needs one GPU per rank; this exercises
 (DDP hooks on the fused nodes, zero bias gradients, grouped geometry prefetch) on the 1-GPU box.
 Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P scripts/ddp_two_ranks_one_gpu.py [rpn_multiclass]
 With the argument `rpn_multiclass` the model is the RPN of hf/configs/rpn_multiclass.config (PointCNN backbone, heads, targets,
-losses: BASELINE config 4), one 16384-point frame per rank."""
+losses: BASELINE config 4), one 16384-point frame per rank.  `rpn_multiclass_graph`: the same model through
+graph_step.TrainStep -- the step replayed from a captured hipGraph, gradients gathered into ONE flat buffer by the captured
+foreach copy, one all-reduce of it, fused Adam on its views (what `bench.py --gpus N` runs below 8 frames per GPU)."""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +23,9 @@ SA = ((512, 1.0, 16, (16, 32)), (128, 2.0, 16, (32, 64)))
 FP = ((64, 64), (32, 32))
 
 
+GRAPH = WORKLOAD == "rpn_multiclass_graph"
+if GRAPH:
+    WORKLOAD = "rpn_multiclass"
 if WORKLOAD == "rpn_multiclass":
     from heterofusionrcnn_amd import rpn as rpn_mod
     CFG = rpn_mod.rpn_multiclass()
@@ -61,15 +66,38 @@ if rank == 1:                       # de-synchronise on purpose: DDP must broadc
     with torch.no_grad():
         for p in model.parameters():
             p.add_(0.5)
-net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
 mine = batch(rank)
 pf = GeometryPrefetcher(model.geometry, depth=2, group=1)
 pf.submit(mine[0])
-opt.zero_grad(set_to_none=True)
-loss_of(net, model, mine, rank, geometry=pf.get()).backward()
-grads = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
-opt.step()
+if GRAPH:
+    from heterofusionrcnn_amd.graph_step import TrainStep, broadcast_parameters
+    broadcast_parameters(model)
+    start = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+    opt = torch.optim.Adam(model.parameters(), lr=0.0, fused=True, capturable=True)    # lr 0 while the constructor warms up and captures
+    inputs = {"xyz": mine[0], "intensity": mine[1], "label_cls": mine[2], "label_reg": mine[3]}
+
+    def seeded_loss(m, inp, geo):      # the dropout masks of shard `rank` fixed as in loss_of()
+        seg_logits, head = m(inp["xyz"], inp["intensity"], geometry=geo)
+        return m.loss(inp["xyz"], seg_logits, head, inp["label_cls"], inp["label_reg"])[0]
+    for mod in model.modules():        # dropout off on both sides: a replay draws from the advancing Philox offset
+        if hasattr(mod, "fc_drop"):
+            mod.fc_drop = [0.0] * len(mod.fc_drop)
+        if hasattr(mod, "drop"):
+            mod.drop = [0.0] * len(mod.drop)
+    step = TrainStep(model, opt, inputs, pf.get(), world=world, graph=True, loss_fn=seeded_loss, warmup=2)
+    assert torch.equal(start, torch.cat([p.detach().flatten() for p in model.parameters()])), "lr 0 moved the weights"
+    for gparam in opt.param_groups:
+        gparam["lr"] = 1e-3
+    step()
+    grads = step.grads.flat.clone()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(step.grads.params, step.grads.views))
+else:
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    opt.zero_grad(set_to_none=True)
+    loss_of(net, model, mine, rank, geometry=pf.get()).backward()
+    grads = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    opt.step()
 weights = torch.cat([p.detach().flatten() for p in model.parameters()])
 both = [torch.empty_like(weights) for _ in range(world)]
 dist.all_gather(both, weights)
@@ -77,6 +105,12 @@ ok = True
 if rank == 0:
     assert torch.equal(both[0], both[1]), "ranks diverged"
     ref = make()
+    if GRAPH:
+        for mod in ref.modules():
+            if hasattr(mod, "fc_drop"):
+                mod.fc_drop = [0.0] * len(mod.fc_drop)
+            if hasattr(mod, "drop"):
+                mod.drop = [0.0] * len(mod.drop)
     per = []
     for r in range(world):          # single process: the mean of the per-shard gradients
         ref.zero_grad(set_to_none=True)

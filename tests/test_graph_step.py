@@ -81,8 +81,9 @@ def _flat_worker(rank, world, port, ret):
     step = TrainStep(model, opt, inputs, geometry={}, world=world, graph=False,
                      loss_fn=lambda m, inp, geo: ((m(inp["x"]) - inp["y"]) ** 2).mean())
     losses = [float(step()) for _ in range(3)]
+    lo, hi = step.grads.flat.data_ptr(), step.grads.flat.data_ptr() + step.grads.flat.numel() * 4
     ret[rank] = {"params": torch.cat([p.detach().flatten() for p in model.parameters()]), "losses": losses,
-                 "views": all(p.grad.data_ptr() >= step.grads.flat.data_ptr() for p in model.parameters())}
+                 "views": all(lo <= p.grad.data_ptr() < hi for p in model.parameters())}
     dp.shutdown(ctx)
 
 

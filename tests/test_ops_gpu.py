@@ -1303,11 +1303,12 @@ def test_mlp_entry_points_reject_bad_arguments(hf):
     assert L.hf_linear_wgrad_workspace(0, 4, 4) == 0
 
 
-@pytest.mark.parametrize("workload", ["stack", "rpn_multiclass"])
+@pytest.mark.parametrize("workload", ["stack", "rpn_multiclass", "rpn_multiclass_graph"])
 def test_two_ddp_ranks_on_one_gpu(hf, workload):
     """scripts/ddp_two_ranks_one_gpu.py: two DistributedDataParallel ranks (gloo) sharing this GPU train the SA/FP
     stack with its fused nodes -- or the RPN of rpn_multiclass.config (PointCNN backbone, heads, losses: BASELINE
-    config 4) -- for one step; gradients equal the mean of the per-shard gradients of a single process"""
+    config 4) -- for one step; gradients equal the mean of the per-shard gradients of a single process.
+    rpn_multiclass_graph: the same through graph_step.TrainStep (captured step, flat gradient buffer, one all-reduce)"""
     import socket, subprocess, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
