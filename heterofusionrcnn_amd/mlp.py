@@ -55,17 +55,18 @@ class _BNReLUTrain(torch.autograd.Function):
 def _splitk_wgrad(g, x, chunk=None):
     """dW = g^T x for tall-skinny g (R,Cout), x (R,Cin): the reduction over R split into chunks (a batched GEMM
     that fills the chip) instead of one workgroup walking all R rows (see modules._TallSkinnyLinear).
-    Chunk sizes from scripts/gemm_pad_probe.py on MI355X: a plain GEMM with R = 65536, 128x196 outputs takes
-    230 us, 64 chunks of 1024 rows 46 us."""
+    Routes by shape from scripts/probes/wgrad_shapes_probe.py on MI355X (us; plain library GEMM / best batched split / MFMA kernel):
+      (131072, 64x3) 285 / 26 / 25     (131072, 64x64) 364 / 26 / 22    (131072, 256x320) 372 / 178 (4096-row chunks) / 234
+      (16384, 64x24) 115 / 25 / 15      (16384, 256x256) 102 / 27 / 32    (32768, 256x320) 141 / 50 (2048) / 90
+      (1048576, 64x3) 1881 / 75 (4096) / 132                              (1048576, 64x64) 1541 / 113 / 110"""
     r = x.shape[0]
+    out = g.shape[1] * x.shape[1]
     if chunk is None:
-        # ~256 chunks: 4096 rows each at a million rows (8 frames), 256 at 65 536 (one frame) -- 32 chunks of 4096 left the
-        # one-frame step with 32 workgroups per weight gradient (111 us each, profiles/r03_bench_1frame_graph_kernel_stats.csv)
-        chunk = 4096 if r >= (1 << 20) else (1024 if r >= (1 << 18) else (512 if r >= (1 << 17) else 256))
-    if r < 32 * chunk or g.shape[1] * x.shape[1] > 512 * 512:
-        # too few rows for a batched split: the MFMA kernel cuts them into chunks itself (8192 rows, 256x256: 30 us
-        # against 53 us for the plain library GEMM)
-        return linear_wgrad(g.contiguous(), x.contiguous()) if 512 <= r and g.shape[1] * x.shape[1] <= 512 * 512 else g.t() @ x
+        if 512 <= r <= (1 << 18) and out <= 128 * 128:
+            return linear_wgrad(g.contiguous(), x.contiguous())   # small results: the MFMA kernel cuts the rows into chunks itself
+        chunk = 4096 if r >= (1 << 17) else (2048 if r >= (1 << 15) else 1024)
+    if r < 8 * chunk or out > 512 * 512:
+        return linear_wgrad(g.contiguous(), x.contiguous()) if 512 <= r and out <= 512 * 512 else g.t() @ x
     main = (r // chunk) * chunk
     gw = torch.bmm(g[:main].view(-1, chunk, g.shape[1]).transpose(1, 2), x[:main].view(-1, chunk, x.shape[1])).sum(dim=0)
     if main < r:
@@ -139,15 +140,17 @@ class _NarrowLinear(torch.autograd.Function):
 
 def linear_narrow(x, weight, bias):
     """x (.., Cin) -> (.., Cout) with Cout <= 4"""
-    if x.is_cuda and x.dtype == torch.float32 and weight.shape[0] <= 4 and x.numel() // x.shape[-1] >= 32768:
+    if x.is_cuda and x.dtype == torch.float32 and weight.shape[0] <= 4 and x.numel() // x.shape[-1] >= 2048:
         y = _NarrowLinear.apply(x.reshape(-1, x.shape[-1]).contiguous(), weight, bias)
         return y.reshape(*x.shape[:-1], weight.shape[0])
     return torch.nn.functional.linear(x, weight, bias)
 
 
 def linear_nobias(x, weight):
-    """x (.., Cin) @ weight (Cout, Cin)^T; tall inputs on the device take the split-K weight gradient"""
-    if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= 32768:
+    """x (.., Cin) @ weight (Cout, Cin)^T; tall inputs on the device take the split-K weight gradient (from 2048 rows: the
+    library's plain weight-gradient GEMM is one workgroup per output tile walking every row -- 115 us for 16384 rows x 64 x 24,
+    the per-layer cost of the one-frame-per-GPU step)"""
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= 2048:
         y = _LinearSplitK.apply(x.reshape(-1, x.shape[-1]).contiguous(), weight)
         return y.reshape(*x.shape[:-1], weight.shape[0])
     return torch.nn.functional.linear(x, weight)
