@@ -1007,7 +1007,8 @@ def test_iou3d_and_nms_adapters(hf, oracle_mod):
 
 
 @pytest.mark.parametrize("rows,c,relu", [(5000, 32, True), (777, 96, True), (4096, 196, False), (300, 7, True),
-                                         (70000, 64, True), (33, 256, True)])
+                                         (70000, 64, True), (33, 256, True), (1024, 64, True), (1025, 64, True), (2, 8, True),
+                                         (64, 1280, False), (1500, 20, True)])
 def test_fused_bn_relu_against_torch(hf, rows, c, relu):
     """csrc/mlp.hip vs nn.BatchNorm1d(eps=1e-3, momentum=0.1) [+ relu]: forward, backward, running stats, eval"""
     from heterofusionrcnn_amd.mlp import BatchNormReLU
@@ -1537,7 +1538,7 @@ def test_fused_linear_bn_relu_maxpool_node(hf, groups, k, cin, cout):
     torch.testing.assert_close(e2, e1, rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("rows,c", [(1000, 64), (4099, 76), (300, 7)])
+@pytest.mark.parametrize("rows,c", [(1000, 64), (4099, 76), (300, 7), (64, 1024), (2048, 8)])
 def test_bn_with_elu_on_load(hf, rows, c):
     """BatchNormReLU(elu_in=True) = batch_norm(elu(x)) of pointfly.dense (pointfly.py:371-497), forward, running statistics
     and all gradients, against torch in fp64"""
