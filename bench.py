@@ -512,6 +512,9 @@ def parse_args(argv=None):
                     help="batches whose geometry is computed in one launch (0 = the largest divisor of --steps up to 16, "
                          "so that the timed steps contain exactly as many geometry launches as they consume)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the 1-core CPU leg (0: 4 for rpn_multiclass, else 24)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks that all use GPU 0 with gloo collectives: the whole multi-rank code path of this script on a "
+                         "one-GPU box (RCCL needs one GPU per rank); the figure it prints is not a scaling measurement")
     ap.add_argument("--stub", action="store_true",
                     help="CPU test hook: the ranks join a gloo group and time a stand-in step (no HIP); exercises the "
                          "launcher / barrier / max-over-ranks / one-JSON-line plumbing without a GPU")
@@ -597,7 +600,7 @@ def main():
     os.dup2(2, 1)
 
     from heterofusionrcnn_amd import dp
-    ctx = dp.init("nccl")   # RCCL; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher
+    ctx = dp.init("nccl", share_gpu=args.rehearse_on_one_gpu)   # RCCL; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher
     world, rank, local_rank = ctx.world, ctx.rank, ctx.local_rank
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("bench.py --gpus %d was started by a launcher with WORLD_SIZE=%d" % (args.gpus, world))
@@ -732,7 +735,8 @@ def main():
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "ranks": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload,
+            "config": {"workload": workload, **({"rehearsal": "all ranks on GPU 0, gloo collectives: not a scaling measurement"}
+                                                if args.rehearse_on_one_gpu else {}),
                        "frames_per_gpu": per_gpu, "global_batch": world * per_gpu, "parallelism": "dp%d" % world,
                        "hip_graph": use_graph,
                        "gradient_exchange": ("none (1 rank)" if world == 1 else

@@ -29,16 +29,22 @@ class DPContext:
         return self.world > 1 or (dist.is_available() and dist.is_initialized())
 
 
-def init(backend=None):
+def init(backend=None, share_gpu=False):
     """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torch.distributed.run sets
-    them) and join the process group.  backend: "nccl" (= RCCL) on GPUs, "gloo" on CPU."""
+    them) and join the process group.  backend: "nccl" (= RCCL) on GPUs, "gloo" on CPU.
+    share_gpu: every rank uses GPU 0 and the collectives go over gloo (CUDA tensors staged through the host) -- a rehearsal of
+    the N > 1 code path on a one-GPU box; RCCL itself needs one GPU per rank."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
     if backend is None:
         backend = "nccl" if use_cuda else "gloo"
-    device = torch.device("cuda", local_rank) if (use_cuda and backend == "nccl") else torch.device("cpu")
+    if share_gpu and use_cuda:
+        backend = "gloo"
+        device = torch.device("cuda", 0)
+    else:
+        device = torch.device("cuda", local_rank) if (use_cuda and backend == "nccl") else torch.device("cpu")
     if device.type == "cuda":
         torch.cuda.set_device(device)
     # HF_FORCE_DDP=1 joins a one-rank group too, so the whole DDP code path can be exercised on a single GPU
@@ -80,7 +86,7 @@ def wrap_model(model, ctx, bucket_cap_mb=64):
     if ctx.device.type == "cuda":
         # per-replica BatchNorm statistics as under Horovod (hf/core/trainer.py:71 averages gradients only):
         # no per-step broadcast of the running buffers
-        return DistributedDataParallel(model, device_ids=[ctx.local_rank], bucket_cap_mb=bucket_cap_mb,
+        return DistributedDataParallel(model, device_ids=[ctx.device.index], bucket_cap_mb=bucket_cap_mb,
                                        gradient_as_bucket_view=True, broadcast_buffers=False)
     return DistributedDataParallel(model, bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
 

@@ -50,4 +50,5 @@ for (clouds, n, m, r, k) in shapes:
         res[name] = {"us": round(us, 2), "us_per_cloud": round(us / clouds, 3), "frac_two_op_bytes": round(alg / (us * 1e-6) / 8e12, 4)}
     out["%dx%dx%d r%.1f k%d" % (clouds, n, m, r, k)] = res
     print(clouds, n, m, r, k, res, flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out", "r3"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r3", "bq_sorted_timing%s.json" % os.environ.get("HF_BQ_G", "")), "w"), indent=1)

@@ -295,3 +295,24 @@ def test_full_width_xconv_level_equals_op_by_op_form():
     for nm, a, r in zip(names, grads, ref_grads):
         scale = float(r.abs().max()) + 1e-6
         assert float((a - r).abs().max()) <= 5e-3 * scale + 1e-4 * gmax, (nm, float((a - r).abs().max()), scale, gmax)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_two_ranks_rehearsed_on_one_gpu(mode):
+    """`bench.py --gpus 2` end to end with both ranks on this GPU and gloo collectives (RCCL needs one GPU per rank): the
+    self-launch, rank-sharded frames, parameter broadcast, the gradient exchange (weak: DistributedDataParallel at 8 frames per
+    rank; strong: the captured step at 4 frames per rank, flat gradient buffer, one all-reduce), barrier + max-over-ranks timing,
+    ONE JSON line from rank 0"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--scaling", mode, "--steps", "4",
+                          "--warmup", "1", "--no-op-table", "--no-cpu-baseline", "--no-side-runs"], capture_output=True, text=True, timeout=500, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    per = 8 if mode == "weak" else 4
+    assert d["n_gpus"] == 2 and d["scaling"] == mode and d["config"]["frames_per_gpu"] == per and d["config"]["global_batch"] == 2 * per
+    assert d["config"]["hip_graph"] == (mode == "strong") and np.isfinite(d["value"]) and d["value"] > 0
+    assert "rehearsal" in d["config"]
