@@ -97,6 +97,9 @@ _SIGNATURES = {
     "hf_depthwise_k_grad": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_xconv_depthwise": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_xconv_depthwise_grad": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hf_xconv_depthwise_gather": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hf_xconv_depthwise_gather_grad": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp],
     "hf_version": [],
     "hf_strerror": [_i],
     "hf_last_hip_error": [],

@@ -39,6 +39,12 @@ template <int N> __device__ __forceinline__ float vec_get(const typename FpsVec<
 template <> __device__ __forceinline__ float vec_get<1>(const float &v, int) { return v; }
 template <int N> __device__ __forceinline__ void vec_set(typename FpsVec<N>::type &v, int i, float f) { v[i] = f; }
 template <> __device__ __forceinline__ void vec_set<1>(float &v, int, float f) { v = f; }
+template <int N> struct FpsIVec { typedef int type __attribute__((ext_vector_type(N))); };
+template <> struct FpsIVec<1> { typedef int type; };
+template <int N> __device__ __forceinline__ int ivec_get(const typename FpsIVec<N>::type &v, int i) { return v[i]; }
+template <> __device__ __forceinline__ int ivec_get<1>(const int &v, int) { return v; }
+template <int N> __device__ __forceinline__ void ivec_set(typename FpsIVec<N>::type &v, int i, int f) { v[i] = f; }
+template <> __device__ __forceinline__ void ivec_set<1>(int &v, int, int f) { v = f; }
 
 // block-level pick among the per-wave slots; every wave computes the same winner.  Lanes replicate
 // slot (lane & (NW-1)) in each DPP row, so 4-step row reductions suffice; the winner's record is then
@@ -173,6 +179,23 @@ __global__ __launch_bounds__(NT) void fps_onchip_kernel(int n, int m, const floa
 // Only touched buckets recompute their maximum; a wave whose buckets were all skipped re-posts
 // its cached candidate.  The block-level pick and the tie rule are those of the plain kernel.
 // ------------------------------------------------------------------------------------------
+// Diagnostic build only (-DHF_FPS_STAMPS, scripts/probes/fps_stamps.py): wave 0 of every workgroup sums the shader
+// cycles of the sections of a round.  The product library is built without it.
+#ifdef HF_FPS_STAMPS
+__device__ unsigned long long g_fps_stamps[64 * 8];
+#define HF_FPS_STAMP(i)                                                                                               \
+    do {                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        unsigned long long ts_;                                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                                   \
+        stamp_sum[i] += ts_ - stamp_last;                                                                             \
+        stamp_last = ts_;                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
+#else
+#define HF_FPS_STAMP(i)
+#endif
+
 constexpr int kFpsCellBits = 12;
 constexpr int kFpsCells = 1 << kFpsCellBits;
 
@@ -182,11 +205,12 @@ struct FpsBucketShared {
     FpsSlot slots[2][kFpsMaxWaves];
 };
 
-template <int PPT>
-__global__ __launch_bounds__(1024) void fps_bucket_kernel(int n, int m, const float *__restrict__ xyz,
-                                                          int *__restrict__ out)
+template <int PPT, int NT>
+__global__ __launch_bounds__(NT) void fps_bucket_kernel(int n, int m, const float *__restrict__ xyz,
+                                                        int *__restrict__ out)
 {
-    constexpr int kFpsThreads = 1024, kFpsWaves = 16;
+    constexpr int kFpsThreads = NT, kFpsWaves = NT / 64;
+    static_assert(PPT <= 32, "one bucket per lane of the low half-wave at most (32-bit touch mask)");
     __shared__ FpsBucketShared sh;
     __shared__ int cellstart[kFpsCells];
     __shared__ unsigned short order[kFpsThreads * PPT];   // sorted position -> original point index
@@ -199,6 +223,7 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int n, int m, const fl
 
     // ---------------- prologue 1: bounding box, cell of every point ----------------
     if (t < 3) { sh.bmin[t] = 0xffffffffu; sh.bmax[t] = 0u; }
+    if (t < kFpsMaxWaves) sh.wsum[t] = 0;   // block_exclusive_scan sums 16 wave slots; a 512-thread group fills 8
     for (int c = t; c < kFpsCells; c += kFpsThreads) cellstart[c] = 0;
     __syncthreads();
     {
@@ -273,9 +298,14 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int n, int m, const fl
     }
     __syncthreads();
 
-    // ---------------- prologue 3: load the buckets; bucket g = i*16 + wave sits in slot i of this wave ----------------
-    float x[PPT], y[PPT], z[PPT];
-    int td[PPT];
+    // ---------------- prologue 3: load the buckets; bucket g = i*kFpsWaves + wave sits in slot i of this wave ----------------
+    // x / y / z / running distance as ext vectors: the rounds below index them with a wave-uniform slot number taken from a bit
+    // mask (s_set_gpr_idx / v_movrel).  A chain of `if (mask >> i & 1)` over all PPT slots cost a scalar branch per slot and
+    // loop -- 32 branches a round, most of a round's time (scripts/probes/fps_stamps.py).  Measured and dropped: a binary tree of
+    // branches to per-slot code (instruction-cache misses: 2.0 us per round), the running distance in LDS with the lanes that
+    // hold a bucket's maximum cached per bucket (0.92), 32 slots as two 16-wide halves behind a branch (1.18).
+    typename FpsVec<PPT>::type x, y, z;
+    typename FpsIVec<PPT>::type td;
     // lane i (< PPT) keeps the box and the maximum running distance of bucket i
     float bx0 = 0.f, bx1 = 0.f, by0 = 0.f, by1 = 0.f, bz0 = 0.f, bz1 = 0.f;
     int bmaxv = -1;
@@ -284,13 +314,14 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int n, int m, const fl
         const int p = (i * kFpsWaves + wave) * 64 + lane;
         const bool ok = p < n;
         const int k = ok ? order[p] : 0;
-        x[i] = pts[k * 3 + 0];
-        y[i] = pts[k * 3 + 1];
-        z[i] = pts[k * 3 + 2];
-        td[i] = ok ? __float_as_int(1e38f) : -1;  // -1 is never raised by min(), never wins
-        const unsigned lx = wave_min_u32(ok ? f2ord(x[i]) : 0xffffffffu), hx = wave_max_u32(ok ? f2ord(x[i]) : 0u);
-        const unsigned ly = wave_min_u32(ok ? f2ord(y[i]) : 0xffffffffu), hy = wave_max_u32(ok ? f2ord(y[i]) : 0u);
-        const unsigned lz = wave_min_u32(ok ? f2ord(z[i]) : 0xffffffffu), hz = wave_max_u32(ok ? f2ord(z[i]) : 0u);
+        const float px = pts[k * 3 + 0], py = pts[k * 3 + 1], pz = pts[k * 3 + 2];
+        vec_set<PPT>(x, i, px);
+        vec_set<PPT>(y, i, py);
+        vec_set<PPT>(z, i, pz);
+        ivec_set<PPT>(td, i, ok ? __float_as_int(1e38f) : -1);  // -1 is never raised by min(), never wins
+        const unsigned lx = wave_min_u32(ok ? f2ord(px) : 0xffffffffu), hx = wave_max_u32(ok ? f2ord(px) : 0u);
+        const unsigned ly = wave_min_u32(ok ? f2ord(py) : 0xffffffffu), hy = wave_max_u32(ok ? f2ord(py) : 0u);
+        const unsigned lz = wave_min_u32(ok ? f2ord(pz) : 0xffffffffu), hz = wave_max_u32(ok ? f2ord(pz) : 0u);
         const bool any = __ballot(ok) != 0ull;
         if (lane == i) {
             bx0 = ord2f(lx); bx1 = ord2f(hx); by0 = ord2f(ly); by1 = ord2f(hy); bz0 = ord2f(lz); bz1 = ord2f(hz);
@@ -305,7 +336,12 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int n, int m, const fl
     int c_dist = -1, c_k = 0;
     float c_x = 0.f, c_y = 0.f, c_z = 0.f;
 
+#ifdef HF_FPS_STAMPS
+    unsigned long long stamp_sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     for (int j = 1; j < mm; ++j) {
+        HF_FPS_STAMP(0);
         // ---- which of my wave's buckets can change? (lanes 0..PPT-1, one bucket each) ----
         const float ex = fmaxf(fmaxf(bx0 - x1, x1 - bx1), 0.0f);
         const float ey = fmaxf(fmaxf(by0 - y1, y1 - by1), 0.0f);
@@ -313,43 +349,48 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int n, int m, const fl
         const float lb = ex * ex + ey * ey + ez * ez;
         const bool need = bmaxv >= 0 && !(lb * 0.99999f > __int_as_float(bmaxv));
         const unsigned mask = static_cast<unsigned>(__ballot(need));
+        HF_FPS_STAMP(1);
         if (mask != 0u) {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) {
-                if ((mask >> i) & 1u) {
-                    const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
-                    const float d = dx * dx + dy * dy + dz * dz;
-                    const int s = min(__float_as_int(d), td[i]);
-                    td[i] = s;
-                    const int nb = static_cast<int>(wave_max_u32(static_cast<unsigned>(s + 1))) - 1;
-                    if (lane == i) bmaxv = nb;
-                }
+            for (unsigned todo = mask; todo != 0u; todo &= todo - 1u) {
+                const int i = __builtin_ctz(todo);  // wave-uniform
+                const float dx = vec_get<PPT>(x, i) - x1, dy = vec_get<PPT>(y, i) - y1, dz = vec_get<PPT>(z, i) - z1;
+                const float d = dx * dx + dy * dy + dz * dz;
+                const int s = min(__float_as_int(d), ivec_get<PPT>(td, i));
+                ivec_set<PPT>(td, i, s);
+                const int nb = static_cast<int>(wave_max_u32(static_cast<unsigned>(s + 1))) - 1;
+                if (lane == i) bmaxv = nb;
             }
+            HF_FPS_STAMP(2);
             // ---- this wave's best point: max distance, then the reference's tie key ----
             const int wbest = static_cast<int>(wave_max_u32(static_cast<unsigned>(bmaxv + 1))) - 1;
             c_dist = wbest;
             if (wbest >= 0) {
-                const unsigned eq = static_cast<unsigned>(__ballot(bmaxv == wbest));
                 unsigned bestkey = 0xffffffffu;
-#pragma unroll
-                for (int i = 0; i < PPT; ++i) {
-                    if ((eq >> i) & 1u) {
-                        const bool match = td[i] == wbest;
-                        const int korig = order[(i * kFpsWaves + wave) * 64 + lane];
+                for (unsigned eq = static_cast<unsigned>(__ballot(bmaxv == wbest)); eq != 0u; eq &= eq - 1u) {
+                    const int i = __builtin_ctz(eq);
+                    const bool match = ivec_get<PPT>(td, i) == wbest;
+                    const int korig = order[(i * kFpsWaves + wave) * 64 + lane];
+                    unsigned long long cand = __ballot(match);
+                    unsigned kmin;
+                    if (__builtin_popcountll(cand) > 1) {  // rare: the same distance twice inside a bucket
                         const unsigned key = match ? fps_tiekey(korig) : 0xffffffffu;
-                        const unsigned kmin = wave_min_u32(key);
-                        if (kmin < bestkey) {
-                            bestkey = kmin;
-                            const int L = __builtin_ctzll(__ballot(key == kmin));
-                            c_k = __builtin_amdgcn_readlane(korig, L);
-                            c_x = readlane_f(x[i], L);
-                            c_y = readlane_f(y[i], L);
-                            c_z = readlane_f(z[i], L);
-                        }
+                        kmin = wave_min_u32(key);
+                        cand = __ballot(key == kmin);
+                    } else {
+                        kmin = fps_tiekey(__builtin_amdgcn_readlane(korig, __builtin_ctzll(cand)));
+                    }
+                    if (kmin < bestkey) {
+                        bestkey = kmin;
+                        const int L = __builtin_ctzll(cand);
+                        c_k = __builtin_amdgcn_readlane(korig, L);
+                        c_x = readlane_f(vec_get<PPT>(x, i), L);
+                        c_y = readlane_f(vec_get<PPT>(y, i), L);
+                        c_z = readlane_f(vec_get<PPT>(z, i), L);
                     }
                 }
             }
         }
+        HF_FPS_STAMP(3);
         FpsSlot *cur = sh.slots[j & 1];
         if (lane == 0) {
             cur[wave].dist = c_dist;
@@ -358,13 +399,20 @@ __global__ __launch_bounds__(1024) void fps_bucket_kernel(int n, int m, const fl
             cur[wave].y = c_y;
             cur[wave].z = c_z;
         }
+        HF_FPS_STAMP(4);
         __syncthreads();
+        HF_FPS_STAMP(5);
         const FpsPick w = fps_pick_slot<kFpsWaves>(cur, lane);
         x1 = w.x;
         y1 = w.y;
         z1 = w.z;
         if (t == 0) picked[j] = static_cast<unsigned short>(w.k);
+        HF_FPS_STAMP(6);
     }
+#ifdef HF_FPS_STAMPS
+    if (t == 0 && blockIdx.x < 64)
+        for (int i = 0; i < 8; ++i) g_fps_stamps[blockIdx.x * 8 + i] = stamp_sum[i];
+#endif
     __syncthreads();
     for (int j = t; j < m; j += kFpsThreads) o[j] = j < mm ? picked[j] : 0;
 }
@@ -446,11 +494,27 @@ __global__ void gather_point_grad_kernel(int n, int m, long long total, const fl
     }
 }
 
-template <int PPT>
+template <int PPT, int NT>
 static int launch_fps_bucket(int b, int n, int m, const float *inp, int *out, hipStream_t st)
 {
-    hipLaunchKernelGGL((fps_bucket_kernel<PPT>), dim3(b), dim3(1024), 0, st, n, m, inp, out);
+    hipLaunchKernelGGL((fps_bucket_kernel<PPT, NT>), dim3(b), dim3(NT), 0, st, n, m, inp, out);
     return launch_status();
+}
+
+// bucketed kernel: NT threads, one 64-point bucket per (wave, slot), PPT = ceil(n / NT) slots rounded up to a power of two
+template <int NT>
+static int launch_fps_bucket_nt(int b, int n, int m, const float *inp, int *out, hipStream_t st)
+{
+    const int ppt = div_up(n, NT);
+    if (ppt <= 1) return launch_fps_bucket<1, NT>(b, n, m, inp, out, st);
+    if (ppt <= 2) return launch_fps_bucket<2, NT>(b, n, m, inp, out, st);
+    if (ppt <= 4) return launch_fps_bucket<4, NT>(b, n, m, inp, out, st);
+    if (ppt <= 8) return launch_fps_bucket<8, NT>(b, n, m, inp, out, st);
+    if (ppt <= 16) return launch_fps_bucket<16, NT>(b, n, m, inp, out, st);
+    if constexpr (NT <= 512) {
+        if (ppt <= 32) return launch_fps_bucket<32, NT>(b, n, m, inp, out, st);
+    }
+    return HF_EINVAL;
 }
 
 template <int PPT, int NT>
@@ -483,12 +547,10 @@ static int launch_fps_onchip(int b, int n, int m, const float *inp, int *out, hi
     // bucket pruning pays once there are enough rounds to amortise its prologue
     const bool bucket = mode == 2 || (mode == 0 && n >= 8192 && m >= 256);
     if (bucket) {
-        const int ppt = div_up(n, 1024);
-        if (ppt <= 1) return launch_fps_bucket<1>(b, n, m, inp, out, st);
-        if (ppt <= 2) return launch_fps_bucket<2>(b, n, m, inp, out, st);
-        if (ppt <= 4) return launch_fps_bucket<4>(b, n, m, inp, out, st);
-        if (ppt <= 8) return launch_fps_bucket<8>(b, n, m, inp, out, st);
-        return launch_fps_bucket<16>(b, n, m, inp, out, st);
+        // 8 waves of 16 / 32 buckets each: 0.83 us per round at 16384 points against 0.88 with 16 waves (the block-level pick and
+        // the bucket test are repeated by every wave)
+        if (nt != 1024 && n <= 512 * 32) return launch_fps_bucket_nt<512>(b, n, m, inp, out, st);
+        return launch_fps_bucket_nt<1024>(b, n, m, inp, out, st);
     }
     if (nt == 0) nt = n <= 4096 ? 256 : 512;  // fewer, fatter waves: measured faster at every size
     if (nt == 256 && n <= 256 * 16) return launch_fps_plain_nt<256>(b, n, m, inp, out, st);
@@ -499,6 +561,13 @@ static int launch_fps_onchip(int b, int n, int m, const float *inp, int *out, hi
 }  // namespace hf
 
 using namespace hf;
+
+#ifdef HF_FPS_STAMPS
+extern "C" __attribute__((visibility("default"))) int hf_debug_fps_stamps(unsigned long long *host, int nwg)
+{
+    return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(hf::g_fps_stamps), sizeof(unsigned long long) * 8 * nwg));
+}
+#endif
 
 HF_API int hf_fps_onchip_limit(void) { return kFpsMaxPoints; }
 

@@ -212,14 +212,37 @@ __global__ __launch_bounds__(kXcThreads) void depthwise_dw_kernel(long long rows
 // hf_depthwise_k, so the results are bit-identical to the two-kernel route.
 // Mapping: a lane owns ONE channel for the whole kernel (its K x M depthwise weights live in registers, blockIdx.y picks
 // the 64-channel chunk), the four waves of a block walk the rows of a chunk; the row's K x K matrix is wave-uniform.
-template <int K, int M>
-__global__ __launch_bounds__(kXcThreads) void xconv_dw_fwd_kernel(long long rows, int c, int rows_per_block,
+//
+// GATHER: F_* = [F_delta | F gathered] (pointcnn.py:124-127 concat of the lifted coordinates with the neighbours' features) is
+// not materialised either: channels below c0 come from `f` = F_delta (rows x K x c0), the others from the feature table
+// `fts` (clouds x n_src rows x c - c0) through the neighbour table `idx` (rows x K, indices inside the row's cloud).  c0 is a multiple of 64, so a block's 64-channel
+// chunk lies on one side.  The gathered rows (K x the table, 1.1 GB for the last decoder layers) were written by
+// group_point and read back here; now the table (134 MB, L2 / MALL resident) is read in place.
+struct XcSource {
+    const float *base;   // + the lane's channel
+    long long stride;
+    bool gathered;
+};
+
+__device__ __forceinline__ XcSource xc_source(int ch, int c, int c0, const float *f, const float *fts, const int *idx)
+{
+    XcSource s;
+    if (idx == nullptr) { s.base = f + ch; s.stride = c; s.gathered = false; }
+    else if (ch - (ch & 63) < c0) { s.base = f + ch; s.stride = c0; s.gathered = false; }
+    else { s.base = fts + (ch - c0); s.stride = c - c0; s.gathered = true; }
+    return s;
+}
+
+template <int K, int M, bool GATHER>
+__global__ __launch_bounds__(kXcThreads) void xconv_dw_fwd_kernel(long long rows, int c, int c0, int rows_per_block,
                                                                  const float *__restrict__ x, const float *__restrict__ f,
-                                                                 const float *__restrict__ wd, float *__restrict__ out)
+                                                                 const float *__restrict__ fts, const int *__restrict__ idx, int n_src,
+                                                                 int rows_per_cloud, const float *__restrict__ wd, float *__restrict__ out)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int ch = blockIdx.y * 64 + lane;
     const bool live = ch < c;
+    const XcSource src = xc_source(live ? ch : blockIdx.y * 64, c, c0, f, fts, GATHER ? idx : nullptr);
     float w[K][M];
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -230,8 +253,12 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_fwd_kernel(long long rows
     for (long long r = r0 + wave; r < r1; r += kXcThreads / 64) {
         const float *xr = x + r * (K * K);
         float fv[K];
+        const long long tbase = (GATHER && src.gathered) ? static_cast<long long>(static_cast<unsigned>(r) / static_cast<unsigned>(rows_per_cloud)) * n_src : 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) fv[j] = live ? f[(r * K + j) * c + ch] : 0.f;
+        for (int j = 0; j < K; ++j) {
+            const long long srow = (GATHER && src.gathered) ? tbase + idx[r * K + j] : r * K + j;
+            fv[j] = live ? src.base[srow * src.stride] : 0.f;
+        }
         float o[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) o[m] = 0.f;
@@ -253,15 +280,21 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_fwd_kernel(long long rows
 // gradients w.r.t. F and Wd, same mapping: per (row, channel) the gradient of F_X (K values), F_X itself (recomputed) and
 // the K input gradients stay in registers; a lane sums its channel's K x M weight gradients over its rows and adds them
 // to grad_wd with one atomic per coefficient (grad_wd zero-filled by the entry point)
-template <int K, int M>
-__global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long rows, int c, int rows_per_block,
+// GATHER: grad_f is the gradient of F_delta only (rows x K x c0); the gathered channels' gradient goes to the feature table
+// through xconv_dw_bwd_fts_kernel
+template <int K, int M, bool GATHER>
+__global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long rows, int c, int c0, int rows_per_block,
                                                                     const float *__restrict__ x, const float *__restrict__ f,
-                                                                    const float *__restrict__ wd, const float *__restrict__ grad_out,
-                                                                    float *__restrict__ grad_f, float *__restrict__ grad_wd)
+                                                                    const float *__restrict__ fts, const int *__restrict__ idx, int n_src,
+                                                                    int rows_per_cloud, const float *__restrict__ wd,
+                                                                    const float *__restrict__ grad_out, float *__restrict__ grad_f,
+                                                                    float *__restrict__ grad_wd)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int ch = blockIdx.y * 64 + lane;
     const bool live = ch < c;
+    const XcSource src = xc_source(live ? ch : blockIdx.y * 64, c, c0, f, fts, GATHER ? idx : nullptr);
+    if (GATHER && src.gathered && !grad_wd) return;   // nothing of this chunk is asked for
     float w[K][M], gw[K][M];
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -272,8 +305,12 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long r
     for (long long r = r0 + wave; r < r1; r += kXcThreads / 64) {
         const float *xr = x + r * (K * K);
         float fv[K], g[M], gfx[K];
+        const long long tbase = (GATHER && src.gathered) ? static_cast<long long>(static_cast<unsigned>(r) / static_cast<unsigned>(rows_per_cloud)) * n_src : 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) fv[j] = live ? f[(r * K + j) * c + ch] : 0.f;
+        for (int j = 0; j < K; ++j) {
+            const long long srow = (GATHER && src.gathered) ? tbase + idx[r * K + j] : r * K + j;
+            fv[j] = live ? src.base[srow * src.stride] : 0.f;
+        }
 #pragma unroll
         for (int m = 0; m < M; ++m) g[m] = live ? grad_out[(r * c + ch) * M + m] : 0.f;
 #pragma unroll
@@ -288,13 +325,13 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long r
 #pragma unroll
             for (int m = 0; m < M; ++m) gw[k][m] = gw[k][m] + t * g[m];   // = hf_depthwise_k_grad's dw
         }
-        if (live && grad_f) {
+        if (live && grad_f && !(GATHER && src.gathered)) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 float a = xr[j] * gfx[0];                                  // = hf_xconv_apply_grad's dF (X transposed)
 #pragma unroll
                 for (int k = 1; k < K; ++k) a = a + xr[k * K + j] * gfx[k];
-                grad_f[(r * K + j) * c + ch] = a;
+                grad_f[(r * K + j) * src.stride + ch] = a;
             }
         }
     }
@@ -320,10 +357,11 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long r
 
 // gradient w.r.t. X: dX[r][k][j] = sum_ch dF_X[r][k][ch] * F[r][j][ch] with dF_X rebuilt from grad_out and Wd on the fly;
 // a wave per row, the 64 partial K x K matrices of the lanes meet in LDS (as xconv_dx_kernel)
-template <int K, int M>
-__global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_x_kernel(long long rows, int c, const float *__restrict__ f,
-                                                                   const float *__restrict__ wd, const float *__restrict__ grad_out,
-                                                                   float *__restrict__ grad_x)
+template <int K, int M, bool GATHER>
+__global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_x_kernel(long long rows, int c, int c0, const float *__restrict__ f,
+                                                                   const float *__restrict__ fts, const int *__restrict__ idx, int n_src,
+                                                                   int rows_per_cloud, const float *__restrict__ wd,
+                                                                   const float *__restrict__ grad_out, float *__restrict__ grad_x)
 {
     extern __shared__ float lds[];
     constexpr int KK = K * K, STRIDE = KK + 1;
@@ -337,10 +375,15 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_x_kernel(long long ro
         for (int i = 0; i < K; ++i)
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[i][j] = 0.f;
+        const long long tbase = GATHER ? static_cast<long long>(static_cast<unsigned>(r) / static_cast<unsigned>(rows_per_cloud)) * n_src : 0;
         for (int ch = lane; ch < c; ch += 64) {
             float fv[K], g[M];
+            const XcSource src = xc_source(ch, c, c0, f, fts, GATHER ? idx : nullptr);
 #pragma unroll
-            for (int j = 0; j < K; ++j) fv[j] = f[(r * K + j) * c + ch];
+            for (int j = 0; j < K; ++j) {
+                const long long srow = (GATHER && src.gathered) ? tbase + idx[r * K + j] : r * K + j;
+                fv[j] = src.base[srow * src.stride];
+            }
 #pragma unroll
             for (int m = 0; m < M; ++m) g[m] = grad_out[(r * c + ch) * M + m];
 #pragma unroll
@@ -365,6 +408,62 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_x_kernel(long long ro
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// gradient w.r.t. the gathered feature table (GATHER mode): table row s collects, in ascending (row, slot) order (the CSR
+// lists of hf_index_inverse, as hf_group_point_grad_gather sums them), the dF of every neighbour slot that read it,
+//   dF[r][j][ch] = sum_k X[r][k][j] * (sum_m grad_out[r][ch*M+m] * Wd[k][ch][m]),
+// rebuilt from grad_out on the fly with the multiply / add order of xconv_dw_bwd_fw_kernel: the (rows x K x c1) gradient
+// of the gathered block is never written.  Same mapping as the forward: a lane owns a channel of the table, the waves of a
+// block walk a chunk of table rows; list entries and the X column are wave-uniform.
+template <int K, int M>
+__global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fts_kernel(long long src_rows, int n_src, long long rows_per_cloud,
+                                                                     int c, int c0, int rows_per_block,
+                                                                     const float *__restrict__ x, const float *__restrict__ wd,
+                                                                     const float *__restrict__ grad_out,
+                                                                     const int *__restrict__ offsets, const int *__restrict__ entries,
+                                                                     float *__restrict__ grad_fts)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int c1 = c - c0, cf = blockIdx.y * 64 + lane, ch = c0 + cf;
+    const bool live = cf < c1;
+    float w[K][M];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int m = 0; m < M; ++m) w[k][m] = live ? wd[(static_cast<size_t>(k) * c + ch) * M + m] : 0.f;
+    const long long s0 = static_cast<long long>(blockIdx.x) * rows_per_block;
+    const long long s1 = s0 + rows_per_block < src_rows ? s0 + rows_per_block : src_rows;
+    long long bb = s0 / n_src;
+    for (long long s = s0 + wave; s < s1; s += kXcThreads / 64) {
+        while (s >= (bb + 1) * n_src) ++bb;
+        const int pt = static_cast<int>(s - bb * n_src);
+        const int *off = offsets + bb * (n_src + 1);
+        const int *ent = entries + bb * rows_per_cloud * K;
+        const int lo = off[pt], hi = off[pt + 1];
+        float acc = 0.f;
+        for (int e = lo; e < hi; ++e) {
+            const int slot = ent[e];
+            const long long r = bb * rows_per_cloud + slot / K;
+            const int j = slot % K;
+            const float *xr = x + r * (K * K);
+            float g[M], gfx[K];
+#pragma unroll
+            for (int m = 0; m < M; ++m) g[m] = live ? grad_out[(r * c + ch) * M + m] : 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; ++m) a = a + g[m] * w[k][m];
+                gfx[k] = a;
+            }
+            float a = xr[j] * gfx[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) a = a + xr[k * K + j] * gfx[k];
+            acc += a;
+        }
+        if (live) grad_fts[s * c1 + cf] = acc;
     }
 }
 
@@ -507,25 +606,23 @@ static void xdw_grid(long long rows, int c, dim3 &grid, int &rows_per_block, int
     grid = dim3(static_cast<unsigned>((rows + rows_per_block - 1) / rows_per_block), cchunks);
 }
 
-HF_API int hf_xconv_depthwise(long long rows, int k, int c, int m, const float *x, const float *f, const float *wd, float *out,
-                              hf_stream_t stream)
+static int xdw_forward(long long rows, int k, int c, int c0, int m, const float *x, const float *f, const float *fts, const int *idx,
+                       int n_src, int rows_per_cloud, const float *wd, float *out, hipStream_t st)
 {
-    if (rows < 0 || c <= 0 || !x || !f || !wd || !out) return HF_EINVAL;
-    if (rows == 0) return HF_OK;
     dim3 grid;
     int rpb;
     xdw_grid(rows, c, grid, rpb);
-#define HF_XDW_FWD(KK, MM) hipLaunchKernelGGL((xconv_dw_fwd_kernel<KK, MM>), grid, dim3(kXcThreads), 0, as_stream(stream), rows, c, rpb, x, f, wd, out);
+#define HF_XDW_FWD(KK, MM)                                                                                             \
+    if (idx) hipLaunchKernelGGL((xconv_dw_fwd_kernel<KK, MM, true>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, out); \
+    else hipLaunchKernelGGL((xconv_dw_fwd_kernel<KK, MM, false>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, out);
     HF_XDW_DISPATCH(HF_XDW_FWD)
 #undef HF_XDW_FWD
     return launch_status();
 }
 
-HF_API int hf_xconv_depthwise_grad(long long rows, int k, int c, int m, const float *x, const float *f, const float *wd,
-                                   const float *grad_out, float *grad_x, float *grad_f, float *grad_wd, hf_stream_t stream)
+static int xdw_backward(long long rows, int k, int c, int c0, int m, const float *x, const float *f, const float *fts, const int *idx,
+                        int n_src, int rows_per_cloud, const float *wd, const float *grad_out, float *grad_x, float *grad_f, float *grad_wd, hipStream_t st)
 {
-    if (rows < 0 || c <= 0 || !x || !f || !wd || !grad_out || (!grad_x && !grad_f && !grad_wd)) return HF_EINVAL;
-    hipStream_t st = as_stream(stream);
     if (grad_wd) {
         const int rc = hip_status(hipMemsetAsync(grad_wd, 0, sizeof(float) * static_cast<size_t>(k) * c * m, st));
         if (rc != HF_OK) return rc;
@@ -538,7 +635,9 @@ HF_API int hf_xconv_depthwise_grad(long long rows, int k, int c, int m, const fl
         // rows per block (one frame per GPU: the deep layers have a few hundred rows)
         xdw_grid(rows, c, grid, rpb, 4);
         if (rpb < 32 && rows > 32) { rpb = 32; grid.x = static_cast<unsigned>((rows + rpb - 1) / rpb); }
-#define HF_XDW_BFW(KK, MM) hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM>), grid, dim3(kXcThreads), 0, st, rows, c, rpb, x, f, wd, grad_out, grad_f, grad_wd);
+#define HF_XDW_BFW(KK, MM)                                                                                             \
+        if (idx) hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, true>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_wd); \
+        else hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, false>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_wd);
         HF_XDW_DISPATCH(HF_XDW_BFW)
 #undef HF_XDW_BFW
         const int rc = launch_status();
@@ -547,17 +646,75 @@ HF_API int hf_xconv_depthwise_grad(long long rows, int k, int c, int m, const fl
     if (grad_x) {
         const size_t lds = sizeof(float) * (kXcThreads / 64) * 64 * (8 * 8 + 1);
         static bool raised = false;
+#define HF_XDW_RAISE(KK, MM, G) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, MM, G>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
 #define HF_XDW_BX(KK, MM)                                                                                              \
         if (!raised) {                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+            HF_XDW_RAISE(KK, 1, false) HF_XDW_RAISE(KK, 2, false) HF_XDW_RAISE(KK, 3, false) HF_XDW_RAISE(KK, 4, false)    \
+            HF_XDW_RAISE(KK, 1, true) HF_XDW_RAISE(KK, 2, true) HF_XDW_RAISE(KK, 3, true) HF_XDW_RAISE(KK, 4, true)        \
             raised = true;                                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((xconv_dw_bwd_x_kernel<KK, MM>), dim3(grid_for(rows, kXcThreads / 64)), dim3(kXcThreads), lds, st, rows, c, f, wd, grad_out, grad_x);
+        if (idx) hipLaunchKernelGGL((xconv_dw_bwd_x_kernel<KK, MM, true>), dim3(grid_for(rows, kXcThreads / 64)), dim3(kXcThreads), lds, st, rows, c, c0, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_x); \
+        else hipLaunchKernelGGL((xconv_dw_bwd_x_kernel<KK, MM, false>), dim3(grid_for(rows, kXcThreads / 64)), dim3(kXcThreads), lds, st, rows, c, c0, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_x);
         HF_XDW_DISPATCH(HF_XDW_BX)
 #undef HF_XDW_BX
+#undef HF_XDW_RAISE
+        return launch_status();
+    }
+    return HF_OK;
+}
+
+HF_API int hf_xconv_depthwise(long long rows, int k, int c, int m, const float *x, const float *f, const float *wd, float *out,
+                              hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !f || !wd || !out) return HF_EINVAL;
+    if (rows == 0) return HF_OK;
+    return xdw_forward(rows, k, c, c, m, x, f, nullptr, nullptr, 0, 1, wd, out, as_stream(stream));
+}
+
+HF_API int hf_xconv_depthwise_grad(long long rows, int k, int c, int m, const float *x, const float *f, const float *wd,
+                                   const float *grad_out, float *grad_x, float *grad_f, float *grad_wd, hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !f || !wd || !grad_out || (!grad_x && !grad_f && !grad_wd)) return HF_EINVAL;
+    return xdw_backward(rows, k, c, c, m, x, f, nullptr, nullptr, 0, 1, wd, grad_out, grad_x, grad_f, grad_wd, as_stream(stream));
+}
+
+HF_API int hf_xconv_depthwise_gather(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
+                                     const float *f_delta, const float *fts, const int *idx, const float *wd, float *out,
+                                     hf_stream_t stream)
+{
+    if (b < 0 || n_src <= 0 || rows_per_cloud < 0 || c0 <= 0 || c0 % 64 != 0 || c1 <= 0) return HF_EINVAL;
+    const long long rows = static_cast<long long>(b) * rows_per_cloud;
+    if (rows == 0) return HF_OK;
+    if (rows > 0x7fffffffll || !x || !f_delta || !fts || !idx || !wd || !out) return HF_EINVAL;
+    return xdw_forward(rows, k, c0 + c1, c0, m, x, f_delta, fts, idx, n_src, rows_per_cloud, wd, out, as_stream(stream));
+}
+
+HF_API int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
+                                          const float *f_delta, const float *fts, const int *idx, const float *wd,
+                                          const float *grad_out, const int *offsets, const int *entries, float *grad_x,
+                                          float *grad_f_delta, float *grad_fts, float *grad_wd, hf_stream_t stream)
+{
+    if (b < 0 || n_src <= 0 || rows_per_cloud < 0 || c0 <= 0 || c0 % 64 != 0 || c1 <= 0 || !x || !f_delta || !fts || !idx || !wd ||
+        !grad_out || static_cast<long long>(b) * rows_per_cloud > 0x7fffffffll || (!grad_x && !grad_f_delta && !grad_fts && !grad_wd))
+        return HF_EINVAL;
+    if (grad_fts && (!offsets || !entries)) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const long long rows = static_cast<long long>(b) * rows_per_cloud;
+    const int c = c0 + c1;
+    if (grad_x || grad_f_delta || grad_wd) {
+        const int rc = xdw_backward(rows, k, c, c0, m, x, f_delta, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_x, grad_f_delta, grad_wd, st);
+        if (rc != HF_OK) return rc;
+    }
+    if (grad_fts) {
+        const long long src_rows = static_cast<long long>(b) * n_src;
+        if (src_rows == 0) return HF_OK;
+        if (rows == 0) return hip_status(hipMemsetAsync(grad_fts, 0, sizeof(float) * static_cast<size_t>(src_rows) * c1, st));
+        dim3 grid;
+        int rpb;
+        xdw_grid(src_rows, c1, grid, rpb);
+#define HF_XDW_FTS(KK, MM) hipLaunchKernelGGL((xconv_dw_bwd_fts_kernel<KK, MM>), grid, dim3(kXcThreads), 0, st, src_rows, n_src, static_cast<long long>(rows_per_cloud), c, c0, rpb, x, wd, grad_out, offsets, entries, grad_fts);
+        HF_XDW_DISPATCH(HF_XDW_FTS)
+#undef HF_XDW_FTS
         return launch_status();
     }
     return HF_OK;

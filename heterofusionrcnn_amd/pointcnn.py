@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from ._lib import check, ptr, stream_ptr
+from ._lib import check, ptr, require, stream_ptr
 from .grouping import INVERSE_MAX_TARGETS, concat_group, group_point, index_inverse, knn_point
 from .sampling import farthest_point_sample, gather_point
 from .mlp import BatchNormReLU, linear_nobias
@@ -263,7 +263,60 @@ class _XConvDepthwise(torch.autograd.Function):
         return (gx.reshape(sx) if gx is not None else None), (gf.reshape(sf) if gf is not None else None), gw
 
 
+class _XConvDepthwiseGather(torch.autograd.Function):
+    """hf_xconv_depthwise_gather (+ grad): the same pass with F_* = [F_delta | fts[idx]] never materialised -- the gathered block
+    (K x the feature table: 1.1 GB at the last decoder layers) is read in place through the neighbour table, and its
+    gradient reaches the table in gather form through the table's CSR inverse"""
+
+    @staticmethod
+    def forward(ctx, x, f_delta, fts, idx, offsets, entries, wd):
+        k, c, m = wd.shape
+        b, p = f_delta.shape[0], f_delta.shape[1]
+        c0, c1, n = f_delta.shape[-1], fts.shape[-1], fts.shape[1]
+        x2, f2, t2, w = x.reshape(-1, k, k).contiguous(), f_delta.reshape(-1, k, c0).contiguous(), fts.contiguous(), wd.contiguous()
+        out = torch.empty((b * p, c * m), dtype=torch.float32, device=fts.device)
+        idx = idx.contiguous()
+        check(_lib.lib().hf_xconv_depthwise_gather(b, n, p, k, c0, c1, m, ptr(x2), ptr(f2), ptr(t2), ptr(idx), ptr(w), ptr(out),
+                                                   stream_ptr()), "xconv_depthwise_gather")
+        ctx.save_for_backward(x2, f2, t2, idx, w, *([offsets, entries] if offsets is not None else []))
+        ctx.dims = (b, p, n, tuple(x.shape), tuple(f_delta.shape))
+        return out.reshape(b, p, c * m)
+
+    @staticmethod
+    def backward(ctx, go):
+        x2, f2, t2, idx, w, *inv = ctx.saved_tensors
+        b, p, n, sx, sf = ctx.dims
+        k, c, m = w.shape
+        c0, c1 = f2.shape[-1], t2.shape[-1]
+        go = go.reshape(-1, c * m).contiguous()
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gf = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        gt = torch.empty_like(t2) if ctx.needs_input_grad[2] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[6] else None
+        require(gt is None or inv, "xconv_depthwise_gather: the gradient of the feature table needs the inverse neighbour table")
+        off, ent = inv if inv else (None, None)
+        check(_lib.lib().hf_xconv_depthwise_gather_grad(b, n, p, k, c0, c1, m, ptr(x2), ptr(f2), ptr(t2), ptr(idx), ptr(w), ptr(go),
+                                                        ptr(off), ptr(ent), ptr(gx), ptr(gf), ptr(gt), ptr(gw), stream_ptr()),
+              "xconv_depthwise_gather_grad")
+        return (gx.reshape(sx) if gx is not None else None), (gf.reshape(sf) if gf is not None else None), gt, None, None, None, gw
+
+
 _XDW_KM = {(8, 1), (8, 2), (8, 3), (8, 4)}
+
+
+def xconv_depthwise_gather(x, f_delta, fts, idx, wd, inverse=None):
+    """xconv_depthwise(x, [f_delta | fts[idx]], wd) without the concatenation in memory.  x (B,P,K,K), f_delta (B,P,K,C0),
+    fts (B,N,C1), idx (B,P,K) int32, wd (K, C0+C1, M); inverse = index_inverse(idx, N) when fts needs a gradient"""
+    off, ent = inverse if inverse is not None else (None, None)
+    return _XConvDepthwiseGather.apply(x, f_delta, fts, idx, off, ent, wd)
+
+
+def _gather_fusable(x, c0, fts, wd, inverse):
+    """the fused kernel's conditions: 64-aligned lifted block, supported (K, M), and -- when the feature table needs a
+    gradient -- the inverse neighbour table to collect it with"""
+    k, c, m = wd.shape
+    return (_hip_ok(x, fts, wd) and (k, m) in _XDW_KM and c0 % 64 == 0 and c0 + fts.shape[-1] == c
+            and (inverse is not None or not (torch.is_grad_enabled() and fts.requires_grad)))
 
 
 def xconv_depthwise(x, f, wd):
@@ -344,7 +397,10 @@ class XConv(nn.Module):
         b, p, k = idx.shape
         local = group_point(pts, idx) - qrs.unsqueeze(2)     # (B,P,K,3)  P' <- P - p
         bn1 = self.lift1.post.bn
-        if fts is not None and _fusable(bn1, fts, self.lift1.linear.out_features, self.lift1.linear.out_features + fts.shape[-1]):
+        gather = self.with_x and fts is not None and _gather_fusable(local, self.lift1.linear.out_features, fts, self.conv.depthwise, inverse)
+        if gather:
+            f = self.lift1(self.lift0(local))                 # F_delta alone: the neighbours' features are read in place below
+        elif fts is not None and _fusable(bn1, fts, self.lift1.linear.out_features, self.lift1.linear.out_features + fts.shape[-1]):
             # F_* <- [F_delta, F]: the second lifting layer's BatchNorm writes into the concat, the gather fills the rest
             z = linear_nobias(self.lift0(local), self.lift1.linear.weight)
             off, ent = inverse if inverse is not None else (None, None)
@@ -359,7 +415,9 @@ class XConv(nn.Module):
             x = self.x1(x).reshape(b, p, k, k)
             x = self.x2(x).reshape(b, p, k, k)
             # F_X <- X x F_*, then the depthwise half of the separable convolution, in one pass
-            zc = linear_nobias(xconv_depthwise(x, f, self.conv.depthwise), self.conv.pointwise.weight)
+            fx = (xconv_depthwise_gather(x, f, fts, idx, self.conv.depthwise, inverse) if gather
+                  else xconv_depthwise(x, f, self.conv.depthwise))
+            zc = linear_nobias(fx, self.conv.pointwise.weight)
             bnc = self.conv.post.bn
             if skip is not None and not self.with_global and _fusable(bnc, zc, zc.shape[-1], zc.shape[-1] + skip.shape[-1]):
                 out = _BNConcatSkip.apply(zc.reshape(-1, zc.shape[-1]), bnc.weight, bnc.bias, bnc.running_mean, bnc.running_var, bnc.eps,

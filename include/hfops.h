@@ -445,6 +445,23 @@ int hf_xconv_depthwise_grad(long long rows, int k, int c, int m, const float *x,
                             const float *grad_out, float *grad_x, float *grad_f, float *grad_wd, hf_stream_t stream);
 int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float *x, const float *w, const float *grad_y,
                         float *grad_x, float *grad_w, hf_stream_t stream);
+/* The same pass with F_* = [F_delta | gathered features] (pointcnn.py:124-127: tf.gather_nd of the previous layer's features
+ * at the neighbour indices, concatenated behind the lifted coordinates) NOT materialised: channels [0, c0) are read from
+ * f_delta (rows, k, c0), channels [c0, c0+c1) from the feature table fts (b, n_src, c1) through the neighbour table
+ * idx (b, rows_per_cloud, k) (indices into the row's own cloud, as hf_group_point takes them); rows = b * rows_per_cloud.
+ * c0 must be a multiple of 64 (it is C/4 of the previous layer in every
+ * shipped configuration).  Results are bit-identical to hf_group_point_into + hf_xconv_depthwise on the concatenation.
+ * hf_xconv_depthwise_gather_grad: grad_x (rows,k,k), grad_f_delta (rows,k,c0), grad_wd (k,c0+c1,m),
+ * grad_fts (b*n_src, c1) -- the last one in gather form through the CSR inverse of the neighbour table (offsets (b, n_src+1),
+ * entries (b, rows_per_cloud*k) from hf_index_inverse): every table row is written once, summed in ascending (row, slot) order
+ * like hf_group_point_grad_gather; no atomics, no zero fill.  Any gradient may be NULL. */
+int hf_xconv_depthwise_gather(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
+                              const float *f_delta, const float *fts, const int *idx, const float *wd, float *out,
+                              hf_stream_t stream);
+int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
+                                   const float *f_delta, const float *fts, const int *idx, const float *wd,
+                                   const float *grad_out, const int *offsets, const int *entries, float *grad_x,
+                                   float *grad_f_delta, float *grad_fts, float *grad_wd, hf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1646,3 +1646,35 @@ def test_group_point_gradient_in_gather_form(hf, oracle_mod):
         g2 = torch.autograd.grad(out2, pts, dev(go))[0]
         np.testing.assert_allclose(host(g2), want, rtol=0, atol=2e-4 * max(1.0, np.abs(want).max()))
         assert not host(g_pts)[:, n - 1].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c0,c1,m", [(64, 256, 1), (64, 1, 4), (128, 96, 2)])
+def test_xconv_depthwise_gather_equals_materialised_concat(c0, c1, m):
+    """hf_xconv_depthwise_gather(+grad) (F_* read in place through the neighbour table) against the route it replaces: concat_group
+    (hf_group_point_into) followed by hf_xconv_depthwise on the materialised (B,P,K,C0+C1) tensor.  Same arithmetic in the same
+    order -> bit-identical output and gradients (the depthwise weights' gradient ends in atomics: 1e-5)."""
+    from heterofusionrcnn_amd import pointcnn as pc
+    from heterofusionrcnn_amd.grouping import concat_group, index_inverse
+    torch.manual_seed(3)
+    b, n, p, k = 3, 500, 200, 8
+    dev = "cuda"
+    x = torch.randn(b, p, k, k, device=dev, requires_grad=True)
+    fd = torch.randn(b, p, k, c0, device=dev, requires_grad=True)
+    fts = torch.randn(b, n, c1, device=dev, requires_grad=True)
+    wd = torch.randn(k, c0 + c1, m, device=dev, requires_grad=True)
+    idx = torch.randint(0, n, (b, p, k), device=dev, dtype=torch.int32)
+    idx[0, :, :] = 7                                      # one table row named by every slot of a cloud, most rows by none
+    inv = index_inverse(idx, n)
+    go = torch.randn(b, p, (c0 + c1) * m, device=dev)
+    ref = pc.xconv_depthwise(x, concat_group(fd, fts, idx, inv), wd)
+    g_ref = torch.autograd.grad(ref, (x, fd, fts, wd), go)
+    out = pc.xconv_depthwise_gather(x, fd, fts, idx, wd, inv)
+    g = torch.autograd.grad(out, (x, fd, fts, wd), go)
+    assert torch.equal(out, ref)
+    for a, r, name in zip(g[:3], g_ref[:3], ("x", "f_delta", "fts")):
+        assert torch.equal(a, r), name
+    assert float((g[3] - g_ref[3]).abs().max()) <= 1e-5 * float(g_ref[3].abs().max())
+    # no gradient asked of the table: no inverse needed
+    out2 = pc.xconv_depthwise_gather(x, fd, fts.detach(), idx, wd)
+    assert torch.equal(out2, ref)
