@@ -99,7 +99,8 @@ _SIGNATURES = {
     "hf_xconv_depthwise_grad": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_xconv_depthwise_gather": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_xconv_depthwise_gather_grad": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                       _vp],
+                                       _vp, _sz, _vp],
+    "hf_xconv_depthwise_gather_grad_workspace": [_i, _i, _i, _i],
     "hf_version": [],
     "hf_strerror": [_i],
     "hf_last_hip_error": [],
@@ -115,6 +116,7 @@ _RESTYPES = {
     "hf_linear_wgrad_workspace": _sz,
     "hf_linear_bn_fwd_workspace": _sz,
     "hf_linear_bn_bwd_workspace": _sz,
+    "hf_xconv_depthwise_gather_grad_workspace": _sz,
     "hf_version": ctypes.c_char_p,
     "hf_strerror": ctypes.c_char_p,
 }

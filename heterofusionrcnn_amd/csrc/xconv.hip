@@ -280,21 +280,22 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_fwd_kernel(long long rows
 // gradients w.r.t. F and Wd, same mapping: per (row, channel) the gradient of F_X (K values), F_X itself (recomputed) and
 // the K input gradients stay in registers; a lane sums its channel's K x M weight gradients over its rows and adds them
 // to grad_wd with one atomic per coefficient (grad_wd zero-filled by the entry point)
-// GATHER: grad_f is the gradient of F_delta only (rows x K x c0); the gathered channels' gradient goes to the feature table
-// through xconv_dw_bwd_fts_kernel
+// GATHER: grad_f is the gradient of F_delta only (rows x K x c0); the gathered channels' gradient is either written to
+// grad_gathered (rows x K x c1, then summed per table row by hf_group_point_grad_gather) or rebuilt per table row by
+// xconv_dw_bwd_fts_kernel
 template <int K, int M, bool GATHER>
 __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long rows, int c, int c0, int rows_per_block,
                                                                     const float *__restrict__ x, const float *__restrict__ f,
                                                                     const float *__restrict__ fts, const int *__restrict__ idx, int n_src,
                                                                     int rows_per_cloud, const float *__restrict__ wd,
                                                                     const float *__restrict__ grad_out, float *__restrict__ grad_f,
-                                                                    float *__restrict__ grad_wd)
+                                                                    float *__restrict__ grad_gathered, float *__restrict__ grad_wd)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int ch = blockIdx.y * 64 + lane;
     const bool live = ch < c;
     const XcSource src = xc_source(live ? ch : blockIdx.y * 64, c, c0, f, fts, GATHER ? idx : nullptr);
-    if (GATHER && src.gathered && !grad_wd) return;   // nothing of this chunk is asked for
+    if (GATHER && src.gathered && !grad_wd && !grad_gathered) return;   // nothing of this chunk is asked for
     float w[K][M], gw[K][M];
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -325,13 +326,14 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long r
 #pragma unroll
             for (int m = 0; m < M; ++m) gw[k][m] = gw[k][m] + t * g[m];   // = hf_depthwise_k_grad's dw
         }
-        if (live && grad_f && !(GATHER && src.gathered)) {
+        float *gdst = (GATHER && src.gathered) ? (grad_gathered ? grad_gathered + (ch - c0) : nullptr) : (grad_f ? grad_f + ch : nullptr);
+        if (live && gdst) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 float a = xr[j] * gfx[0];                                  // = hf_xconv_apply_grad's dF (X transposed)
 #pragma unroll
                 for (int k = 1; k < K; ++k) a = a + xr[k * K + j] * gfx[k];
-                grad_f[(r * K + j) * src.stride + ch] = a;
+                gdst[(r * K + j) * src.stride] = a;
             }
         }
     }
@@ -363,26 +365,40 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_x_kernel(long long ro
                                                                    int rows_per_cloud, const float *__restrict__ wd,
                                                                    const float *__restrict__ grad_out, float *__restrict__ grad_x)
 {
+    // the 64 partial K x K matrices of a wave's lanes are first summed inside each quad of lanes (two DPP adds per entry),
+    // the 16 quad sums meet in LDS: a quarter of the LDS of the one-slot-per-lane form (4.2 KB per wave: 9 blocks per CU
+    // instead of 2, which is what the gathered loads need to stay in flight) and a quarter of its reads
     extern __shared__ float lds[];
-    constexpr int KK = K * K, STRIDE = KK + 1;
+    constexpr int KK = K * K, STRIDE = KK + 1, QUADS = 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float *mine = lds + static_cast<size_t>(w) * 64 * STRIDE;
+    float *mine = lds + static_cast<size_t>(w) * QUADS * STRIDE;
     const long long wave = w + static_cast<long long>(blockIdx.x) * (kXcThreads / 64);
     const long long nwaves = static_cast<long long>(gridDim.x) * (kXcThreads / 64);
+    const int c1 = c - c0;
     for (long long r = wave; r < rows; r += nwaves) {
         float acc[K][K];
 #pragma unroll
         for (int i = 0; i < K; ++i)
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[i][j] = 0.f;
-        const long long tbase = GATHER ? static_cast<long long>(static_cast<unsigned>(r) / static_cast<unsigned>(rows_per_cloud)) * n_src : 0;
+        long long trow[K];   // the K table rows of this row's neighbours, once per row (wave-uniform)
+        if constexpr (GATHER) {
+            const long long tbase = static_cast<long long>(static_cast<unsigned>(r) / static_cast<unsigned>(rows_per_cloud)) * n_src;
+#pragma unroll
+            for (int j = 0; j < K; ++j) trow[j] = tbase + idx[r * K + j];
+        }
         for (int ch = lane; ch < c; ch += 64) {
             float fv[K], g[M];
-            const XcSource src = xc_source(ch, c, c0, f, fts, GATHER ? idx : nullptr);
+            if constexpr (GATHER) {
+                // selects, no branch around the loads
+                const bool gathered = ch >= c0;
+                const float *base = gathered ? fts + (ch - c0) : f + ch;
+                const long long stride = gathered ? c1 : c0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const long long srow = (GATHER && src.gathered) ? tbase + idx[r * K + j] : r * K + j;
-                fv[j] = src.base[srow * src.stride];
+                for (int j = 0; j < K; ++j) fv[j] = base[(gathered ? trow[j] : r * K + j) * stride];
+            } else {
+#pragma unroll
+                for (int j = 0; j < K; ++j) fv[j] = f[(r * K + j) * c + ch];
             }
 #pragma unroll
             for (int m = 0; m < M; ++m) g[m] = grad_out[(r * c + ch) * M + m];
@@ -398,12 +414,18 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_x_kernel(long long ro
 #pragma unroll
         for (int i = 0; i < K; ++i)
 #pragma unroll
-            for (int j = 0; j < K; ++j) mine[lane * STRIDE + i * K + j] = acc[i][j];
+            for (int j = 0; j < K; ++j) {
+                float v = acc[i][j];
+                v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xb1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4e, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+                if ((lane & 3) == 0) mine[(lane >> 2) * STRIDE + i * K + j] = v;
+            }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int p = lane; p < KK; p += 64) {
             float s = 0.f;
-            for (int l = 0; l < 64; ++l) s = s + mine[l * STRIDE + p];
+#pragma unroll
+            for (int l = 0; l < QUADS; ++l) s = s + mine[l * STRIDE + p];
             grad_x[r * KK + p] = s;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -443,25 +465,34 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fts_kernel(long long 
         const int *ent = entries + bb * rows_per_cloud * K;
         const int lo = off[pt], hi = off[pt + 1];
         float acc = 0.f;
-        for (int e = lo; e < hi; ++e) {
-            const int slot = ent[e];
-            const long long r = bb * rows_per_cloud + slot / K;
-            const int j = slot % K;
-            const float *xr = x + r * (K * K);
-            float g[M], gfx[K];
+        // four list entries per trip: their loads are issued together (a dependent scalar load -> row -> vector load chain per
+        // entry kept one load in flight per wave); summed in list order, slots past the end add zero
+        for (int e = lo; e < hi; e += 4) {
+            float a4[4];
 #pragma unroll
-            for (int m = 0; m < M; ++m) g[m] = live ? grad_out[(r * c + ch) * M + m] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const bool valid = e + u < hi;
+                const int slot = ent[valid ? e + u : lo];
+                const long long r = bb * rows_per_cloud + slot / K;
+                const int j = slot % K;
+                const float *xr = x + r * (K * K);
+                float g[M], gfx[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float a = 0.f;
+                for (int m = 0; m < M; ++m) g[m] = live ? grad_out[(r * c + ch) * M + m] : 0.f;
 #pragma unroll
-                for (int m = 0; m < M; ++m) a = a + g[m] * w[k][m];
-                gfx[k] = a;
+                for (int k = 0; k < K; ++k) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) a = a + g[m] * w[k][m];
+                    gfx[k] = a;
+                }
+                float a = xr[j] * gfx[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) a = a + xr[k * K + j] * gfx[k];
+                a4[u] = valid ? a : 0.f;
             }
-            float a = xr[j] * gfx[0];
 #pragma unroll
-            for (int k = 1; k < K; ++k) a = a + xr[k * K + j] * gfx[k];
-            acc += a;
+            for (int u = 0; u < 4; ++u) acc += a4[u];
         }
         if (live) grad_fts[s * c1 + cf] = acc;
     }
@@ -621,14 +652,15 @@ static int xdw_forward(long long rows, int k, int c, int c0, int m, const float 
 }
 
 static int xdw_backward(long long rows, int k, int c, int c0, int m, const float *x, const float *f, const float *fts, const int *idx,
-                        int n_src, int rows_per_cloud, const float *wd, const float *grad_out, float *grad_x, float *grad_f, float *grad_wd, hipStream_t st)
+                        int n_src, int rows_per_cloud, const float *wd, const float *grad_out, float *grad_x, float *grad_f, float *grad_gathered,
+                        float *grad_wd, hipStream_t st)
 {
     if (grad_wd) {
         const int rc = hip_status(hipMemsetAsync(grad_wd, 0, sizeof(float) * static_cast<size_t>(k) * c * m, st));
         if (rc != HF_OK) return rc;
     }
     if (rows == 0) return HF_OK;
-    if (grad_f || grad_wd) {
+    if (grad_f || grad_wd || grad_gathered) {
         dim3 grid;
         int rpb;
         // every block ends in one atomic per weight coefficient on the same k*c*m addresses: 4 blocks per CU, and at least 32
@@ -636,15 +668,15 @@ static int xdw_backward(long long rows, int k, int c, int c0, int m, const float
         xdw_grid(rows, c, grid, rpb, 4);
         if (rpb < 32 && rows > 32) { rpb = 32; grid.x = static_cast<unsigned>((rows + rpb - 1) / rpb); }
 #define HF_XDW_BFW(KK, MM)                                                                                             \
-        if (idx) hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, true>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_wd); \
-        else hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, false>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_wd);
+        if (idx) hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, true>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_gathered, grad_wd); \
+        else hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, false>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_gathered, grad_wd);
         HF_XDW_DISPATCH(HF_XDW_BFW)
 #undef HF_XDW_BFW
         const int rc = launch_status();
         if (rc != HF_OK) return rc;
     }
     if (grad_x) {
-        const size_t lds = sizeof(float) * (kXcThreads / 64) * 64 * (8 * 8 + 1);
+        const size_t lds = sizeof(float) * (kXcThreads / 64) * 16 * (8 * 8 + 1);
         static bool raised = false;
 #define HF_XDW_RAISE(KK, MM, G) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, MM, G>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
 #define HF_XDW_BX(KK, MM)                                                                                              \
@@ -675,7 +707,7 @@ HF_API int hf_xconv_depthwise_grad(long long rows, int k, int c, int m, const fl
                                    const float *grad_out, float *grad_x, float *grad_f, float *grad_wd, hf_stream_t stream)
 {
     if (rows < 0 || c <= 0 || !x || !f || !wd || !grad_out || (!grad_x && !grad_f && !grad_wd)) return HF_EINVAL;
-    return xdw_backward(rows, k, c, c, m, x, f, nullptr, nullptr, 0, 1, wd, grad_out, grad_x, grad_f, grad_wd, as_stream(stream));
+    return xdw_backward(rows, k, c, c, m, x, f, nullptr, nullptr, 0, 1, wd, grad_out, grad_x, grad_f, nullptr, grad_wd, as_stream(stream));
 }
 
 HF_API int hf_xconv_depthwise_gather(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
@@ -689,26 +721,41 @@ HF_API int hf_xconv_depthwise_gather(int b, int n_src, int rows_per_cloud, int k
     return xdw_forward(rows, k, c0 + c1, c0, m, x, f_delta, fts, idx, n_src, rows_per_cloud, wd, out, as_stream(stream));
 }
 
+HF_API size_t hf_xconv_depthwise_gather_grad_workspace(int b, int rows_per_cloud, int k, int c1)
+{
+    if (b <= 0 || rows_per_cloud <= 0 || k <= 0 || c1 <= 0) return 0;
+    return sizeof(float) * static_cast<size_t>(b) * rows_per_cloud * k * c1;
+}
+
 HF_API int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
                                           const float *f_delta, const float *fts, const int *idx, const float *wd,
                                           const float *grad_out, const int *offsets, const int *entries, float *grad_x,
-                                          float *grad_f_delta, float *grad_fts, float *grad_wd, hf_stream_t stream)
+                                          float *grad_f_delta, float *grad_fts, float *grad_wd, void *workspace,
+                                          size_t workspace_bytes, hf_stream_t stream)
 {
     if (b < 0 || n_src <= 0 || rows_per_cloud < 0 || c0 <= 0 || c0 % 64 != 0 || c1 <= 0 || !x || !f_delta || !fts || !idx || !wd ||
-        !grad_out || static_cast<long long>(b) * rows_per_cloud > 0x7fffffffll || (!grad_x && !grad_f_delta && !grad_fts && !grad_wd))
+        !grad_out || static_cast<long long>(b) * rows_per_cloud > 0x7fffffffll ||
+        (!grad_x && !grad_f_delta && !grad_fts && !grad_wd))
         return HF_EINVAL;
     if (grad_fts && (!offsets || !entries)) return HF_EINVAL;
+    if (workspace && workspace_bytes < hf_xconv_depthwise_gather_grad_workspace(b, rows_per_cloud, k, c1)) return HF_EWORKSPACE;
     hipStream_t st = as_stream(stream);
     const long long rows = static_cast<long long>(b) * rows_per_cloud;
     const int c = c0 + c1;
-    if (grad_x || grad_f_delta || grad_wd) {
-        const int rc = xdw_backward(rows, k, c, c0, m, x, f_delta, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_x, grad_f_delta, grad_wd, st);
+    // with a workspace the gathered block's gradient is written once (rows x k x c1) and summed per table row by
+    // hf_group_point_grad_gather (240 us + 230 us of extra writes at the last decoder layer); without one it is rebuilt per
+    // table row from grad_out (no extra memory, 890 us there)
+    float *gathered = (grad_fts && workspace) ? static_cast<float *>(workspace) : nullptr;
+    if (grad_x || grad_f_delta || grad_wd || gathered) {
+        const int rc = xdw_backward(rows, k, c, c0, m, x, f_delta, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_x, grad_f_delta, gathered,
+                                    grad_wd, st);
         if (rc != HF_OK) return rc;
     }
     if (grad_fts) {
         const long long src_rows = static_cast<long long>(b) * n_src;
         if (src_rows == 0) return HF_OK;
         if (rows == 0) return hip_status(hipMemsetAsync(grad_fts, 0, sizeof(float) * static_cast<size_t>(src_rows) * c1, st));
+        if (gathered) return hf_group_point_grad_gather(b, n_src, c1, rows_per_cloud, k, c1, 0, gathered, offsets, entries, grad_fts, stream);
         dim3 grid;
         int rpb;
         xdw_grid(src_rows, c1, grid, rpb);

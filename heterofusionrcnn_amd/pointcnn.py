@@ -269,7 +269,8 @@ class _XConvDepthwiseGather(torch.autograd.Function):
     gradient reaches the table in gather form through the table's CSR inverse"""
 
     @staticmethod
-    def forward(ctx, x, f_delta, fts, idx, offsets, entries, wd):
+    def forward(ctx, x, f_delta, fts, idx, offsets, entries, wd, use_workspace=True):
+        ctx.use_workspace = use_workspace
         k, c, m = wd.shape
         b, p = f_delta.shape[0], f_delta.shape[1]
         c0, c1, n = f_delta.shape[-1], fts.shape[-1], fts.shape[1]
@@ -295,20 +296,24 @@ class _XConvDepthwiseGather(torch.autograd.Function):
         gw = torch.empty_like(w) if ctx.needs_input_grad[6] else None
         require(gt is None or inv, "xconv_depthwise_gather: the gradient of the feature table needs the inverse neighbour table")
         off, ent = inv if inv else (None, None)
-        check(_lib.lib().hf_xconv_depthwise_gather_grad(b, n, p, k, c0, c1, m, ptr(x2), ptr(f2), ptr(t2), ptr(idx), ptr(w), ptr(go),
-                                                        ptr(off), ptr(ent), ptr(gx), ptr(gf), ptr(gt), ptr(gw), stream_ptr()),
+        L = _lib.lib()
+        # the gathered block's gradient is staged once in a workspace (freed right after) and summed per table row
+        nbytes = L.hf_xconv_depthwise_gather_grad_workspace(b, p, k, c1) if (gt is not None and ctx.use_workspace) else 0
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=go.device) if nbytes else None
+        check(L.hf_xconv_depthwise_gather_grad(b, n, p, k, c0, c1, m, ptr(x2), ptr(f2), ptr(t2), ptr(idx), ptr(w), ptr(go),
+                                               ptr(off), ptr(ent), ptr(gx), ptr(gf), ptr(gt), ptr(gw), ptr(ws), nbytes, stream_ptr()),
               "xconv_depthwise_gather_grad")
-        return (gx.reshape(sx) if gx is not None else None), (gf.reshape(sf) if gf is not None else None), gt, None, None, None, gw
+        return (gx.reshape(sx) if gx is not None else None), (gf.reshape(sf) if gf is not None else None), gt, None, None, None, gw, None
 
 
 _XDW_KM = {(8, 1), (8, 2), (8, 3), (8, 4)}
 
 
-def xconv_depthwise_gather(x, f_delta, fts, idx, wd, inverse=None):
+def xconv_depthwise_gather(x, f_delta, fts, idx, wd, inverse=None, use_workspace=True):
     """xconv_depthwise(x, [f_delta | fts[idx]], wd) without the concatenation in memory.  x (B,P,K,K), f_delta (B,P,K,C0),
     fts (B,N,C1), idx (B,P,K) int32, wd (K, C0+C1, M); inverse = index_inverse(idx, N) when fts needs a gradient"""
     off, ent = inverse if inverse is not None else (None, None)
-    return _XConvDepthwiseGather.apply(x, f_delta, fts, idx, off, ent, wd)
+    return _XConvDepthwiseGather.apply(x, f_delta, fts, idx, off, ent, wd, use_workspace)
 
 
 def _gather_fusable(x, c0, fts, wd, inverse):

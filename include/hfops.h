@@ -454,14 +454,18 @@ int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float *x, con
  * hf_xconv_depthwise_gather_grad: grad_x (rows,k,k), grad_f_delta (rows,k,c0), grad_wd (k,c0+c1,m),
  * grad_fts (b*n_src, c1) -- the last one in gather form through the CSR inverse of the neighbour table (offsets (b, n_src+1),
  * entries (b, rows_per_cloud*k) from hf_index_inverse): every table row is written once, summed in ascending (row, slot) order
- * like hf_group_point_grad_gather; no atomics, no zero fill.  Any gradient may be NULL. */
+ * like hf_group_point_grad_gather; no atomics, no zero fill.  Any gradient may be NULL.  workspace
+ * (hf_xconv_depthwise_gather_grad_workspace bytes, may be NULL): with it the gathered block's gradient is written once and summed
+ * per table row (faster); without it it is rebuilt per table row from grad_out (no extra memory).  Same values either way. */
+size_t hf_xconv_depthwise_gather_grad_workspace(int b, int rows_per_cloud, int k, int c1);
 int hf_xconv_depthwise_gather(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
                               const float *f_delta, const float *fts, const int *idx, const float *wd, float *out,
                               hf_stream_t stream);
 int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
                                    const float *f_delta, const float *fts, const int *idx, const float *wd,
                                    const float *grad_out, const int *offsets, const int *entries, float *grad_x,
-                                   float *grad_f_delta, float *grad_fts, float *grad_wd, hf_stream_t stream);
+                                   float *grad_f_delta, float *grad_fts, float *grad_wd, void *workspace, size_t workspace_bytes,
+                                   hf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1669,12 +1669,13 @@ def test_xconv_depthwise_gather_equals_materialised_concat(c0, c1, m):
     go = torch.randn(b, p, (c0 + c1) * m, device=dev)
     ref = pc.xconv_depthwise(x, concat_group(fd, fts, idx, inv), wd)
     g_ref = torch.autograd.grad(ref, (x, fd, fts, wd), go)
-    out = pc.xconv_depthwise_gather(x, fd, fts, idx, wd, inv)
-    g = torch.autograd.grad(out, (x, fd, fts, wd), go)
-    assert torch.equal(out, ref)
-    for a, r, name in zip(g[:3], g_ref[:3], ("x", "f_delta", "fts")):
-        assert torch.equal(a, r), name
-    assert float((g[3] - g_ref[3]).abs().max()) <= 1e-5 * float(g_ref[3].abs().max())
+    for use_ws in (True, False):      # the table's gradient staged in a workspace / rebuilt per table row: the same values
+        out = pc.xconv_depthwise_gather(x, fd, fts, idx, wd, inv, use_workspace=use_ws)
+        g = torch.autograd.grad(out, (x, fd, fts, wd), go)
+        assert torch.equal(out, ref)
+        for a, r, name in zip(g[:3], g_ref[:3], ("x", "f_delta", "fts")):
+            assert torch.equal(a, r), (name, use_ws)
+        assert float((g[3] - g_ref[3]).abs().max()) <= 1e-5 * float(g_ref[3].abs().max())
     # no gradient asked of the table: no inverse needed
     out2 = pc.xconv_depthwise_gather(x, fd, fts.detach(), idx, wd)
     assert torch.equal(out2, ref)
