@@ -79,6 +79,8 @@ _SIGNATURES = {
     "hf_bn_relu_bwd_dx": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "hf_linear_bn_bwd_workspace": [_i],
     "hf_linear_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 18 + [_vp, _sz, _vp],
+    "hf_linear_elu_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_linear_elu_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 10 + [_vp, _sz, _vp],
     "hf_project_gather": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_project_gather_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_fuse_concat": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp],

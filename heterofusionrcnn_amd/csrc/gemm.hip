@@ -237,8 +237,10 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                                                                   const float *__restrict__ in_invstd,
                                                                   const float *__restrict__ W,
                                                                   const float *__restrict__ bias, float *__restrict__ Z,
-                                                                  float *__restrict__ Hout, float *__restrict__ partial)
+                                                                  float *__restrict__ Hout, float *__restrict__ partial, int elu)
 {
+    // elu: the layer order of PointCNN's dense (pointfly.py:480-497), linear -> ELU -> BatchNorm: the activation on load is
+    // a (elu(x) - mu) + beta (no clamp) and the statistics in the epilogue are those of elu(z)
     __shared__ float As[kFwdRows * kFwdLS];
     __shared__ float Bs[NT * 32 * kFwdLS];
     __shared__ float red[4][NT * 32][2];
@@ -284,10 +286,17 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                 if (act) {  // rows / channels outside the matrix stay zero
                     const bool rin = row0 + srow + 32 * p < rows;
                     const int k = kc + k4;
-                    v.x = (rin && k < cin) ? fmaxf(sc[k] * (v.x - smu[k]) + sh[k], 0.f) : 0.f;
-                    v.y = (rin && k + 1 < cin) ? fmaxf(sc[k + 1] * (v.y - smu[k + 1]) + sh[k + 1], 0.f) : 0.f;
-                    v.z = (rin && k + 2 < cin) ? fmaxf(sc[k + 2] * (v.z - smu[k + 2]) + sh[k + 2], 0.f) : 0.f;
-                    v.w = (rin && k + 3 < cin) ? fmaxf(sc[k + 3] * (v.w - smu[k + 3]) + sh[k + 3], 0.f) : 0.f;
+                    if (elu) {
+                        v.x = (rin && k < cin) ? sc[k] * (elu_fwd(v.x) - smu[k]) + sh[k] : 0.f;
+                        v.y = (rin && k + 1 < cin) ? sc[k + 1] * (elu_fwd(v.y) - smu[k + 1]) + sh[k + 1] : 0.f;
+                        v.z = (rin && k + 2 < cin) ? sc[k + 2] * (elu_fwd(v.z) - smu[k + 2]) + sh[k + 2] : 0.f;
+                        v.w = (rin && k + 3 < cin) ? sc[k + 3] * (elu_fwd(v.w) - smu[k + 3]) + sh[k + 3] : 0.f;
+                    } else {
+                        v.x = (rin && k < cin) ? fmaxf(sc[k] * (v.x - smu[k]) + sh[k], 0.f) : 0.f;
+                        v.y = (rin && k + 1 < cin) ? fmaxf(sc[k + 1] * (v.y - smu[k + 1]) + sh[k + 1], 0.f) : 0.f;
+                        v.z = (rin && k + 2 < cin) ? fmaxf(sc[k + 2] * (v.z - smu[k + 2]) + sh[k + 2], 0.f) : 0.f;
+                        v.w = (rin && k + 3 < cin) ? fmaxf(sc[k + 3] * (v.w - smu[k + 3]) + sh[k + 3], 0.f) : 0.f;
+                    }
                     if (Hout && rin && k < cin) {  // the activated input, kept for the weight gradient
                         float *h = Hout + (row0 + srow + 32 * p) * cin + k;
                         if constexpr (VEC) {
@@ -331,8 +340,9 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                 const float v = acc[nt][g] + bv;
                 if (cin_range && row < rows) {
                     Z[row * cout + col] = v;
-                    s1[nt] += v;
-                    s2[nt] += v * v;
+                    const float sv = elu ? elu_fwd(v) : v;
+                    s1[nt] += sv;
+                    s2[nt] += sv * sv;
                 }
             }
         }
@@ -378,8 +388,10 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     const float *__restrict__ invstd, const float *__restrict__ dgamma, const float *__restrict__ dbeta,
     float *__restrict__ DZ_out, const float *__restrict__ WT, float *__restrict__ DX, const float *__restrict__ Zprev,
     const float *__restrict__ p_gamma, const float *__restrict__ p_beta, const float *__restrict__ p_mean,
-    const float *__restrict__ p_invstd, float *__restrict__ partial)
+    const float *__restrict__ p_invstd, float *__restrict__ partial, int elu)
 {
+    // elu (without FROM_DY): the layer below is linear -> ELU -> BatchNorm; DX is the gradient w.r.t. its normalised output, so
+    // its BN-backward sums are sum DX and sum DX * xhat with xhat from elu(z_prev), no mask
     __shared__ float As[kFwdRows * kFwdLS];
     __shared__ float Bs[NT * 32 * kFwdLS];
     __shared__ float red[4][NT * 32][2];
@@ -498,9 +510,14 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                 if (DX) DX[row * ncols + col] = v;
                 if (sums) {
                     const float zp = Zprev[row * ncols + col];
-                    const float dh = (pa[nt] * (zp - pmu[nt]) + psh[nt] > 0.0f) ? v : 0.0f;
-                    s1[nt] += dh;
-                    s2[nt] += dh * ((zp - pmu[nt]) * pis[nt]);
+                    if (elu) {
+                        s1[nt] += v;
+                        s2[nt] += v * ((elu_fwd(zp) - pmu[nt]) * pis[nt]);
+                    } else {
+                        const float dh = (pa[nt] * (zp - pmu[nt]) + psh[nt] > 0.0f) ? v : 0.0f;
+                        s1[nt] += dh;
+                        s2[nt] += dh * ((zp - pmu[nt]) * pis[nt]);
+                    }
                 }
             }
         }
@@ -610,10 +627,10 @@ HF_API size_t hf_linear_bn_fwd_workspace(int cout)
     return cout > 0 ? sizeof(float) * 2 * static_cast<size_t>(cout) * kBnMaxBlocks : 0;
 }
 
-HF_API int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,
-                            const float *in_mean, const float *in_invstd, float *x_act, const float *weight,
-                            const float *bias, float *z, float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd,
-                            void *workspace, size_t workspace_bytes, hf_stream_t stream)
+static int linear_bn_fwd_impl(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,
+                              const float *in_mean, const float *in_invstd, float *x_act, const float *weight,
+                              const float *bias, float *z, float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd,
+                              void *workspace, size_t workspace_bytes, hf_stream_t stream, int elu)
 {
     if (rows <= 0 || cin <= 0 || cout <= 0 || cin > kFwdMaxCin || cout > 256 || !x || !weight || !z || !mean || !invstd)
         return HF_EINVAL;
@@ -628,7 +645,7 @@ HF_API int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, c
     const int nblk = resident_grid(nt, ntiles);
 #define HF_FWD(N, V)                                                                                                    \
     hipLaunchKernelGGL((linear_fwd_kernel<N, V>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, cin, cout, ntiles, x,    \
-                       in_gamma, in_beta, in_mean, in_invstd, weight, bias, z, x_act, partial)
+                       in_gamma, in_beta, in_mean, in_invstd, weight, bias, z, x_act, partial, elu)
 #define HF_FWD_V(N)                                                                                                     \
     case N:                                                                                                             \
         if (vec) HF_FWD(N, true); else HF_FWD(N, false);                                                                \
@@ -643,16 +660,34 @@ HF_API int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, c
     return launch_status();
 }
 
+HF_API int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,
+                            const float *in_mean, const float *in_invstd, float *x_act, const float *weight,
+                            const float *bias, float *z, float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd,
+                            void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    return linear_bn_fwd_impl(rows, cin, cout, x, in_gamma, in_beta, in_mean, in_invstd, x_act, weight, bias, z, eps, momentum, running_mean,
+                              running_var, mean, invstd, workspace, workspace_bytes, stream, 0);
+}
+
+HF_API int hf_linear_elu_bn_fwd(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,
+                                const float *in_mean, const float *in_invstd, float *x_act, const float *weight, float *z, float eps,
+                                float momentum, float *running_mean, float *running_var, float *mean, float *invstd, void *workspace,
+                                size_t workspace_bytes, hf_stream_t stream)
+{
+    return linear_bn_fwd_impl(rows, cin, cout, x, in_gamma, in_beta, in_mean, in_invstd, x_act, weight, nullptr, z, eps, momentum, running_mean,
+                              running_var, mean, invstd, workspace, workspace_bytes, stream, 1);
+}
+
 HF_API size_t hf_linear_bn_bwd_workspace(int cin)
 {
     return cin > 0 ? sizeof(float) * 2 * static_cast<size_t>(cin) * kBnMaxBlocks : 0;
 }
 
-HF_API int hf_linear_bn_bwd(long long rows, int cout, int cin, const float *dy_or_dz, const float *z, const float *gamma,
-                            const float *beta, const float *mean, const float *invstd, const float *dgamma,
-                            const float *dbeta, float *dz_out, const float *weight_t, float *dx, const float *z_prev,
-                            const float *p_gamma, const float *p_beta, const float *p_mean, const float *p_invstd,
-                            float *p_dgamma, float *p_dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+static int linear_bn_bwd_impl(long long rows, int cout, int cin, const float *dy_or_dz, const float *z, const float *gamma,
+                              const float *beta, const float *mean, const float *invstd, const float *dgamma,
+                              const float *dbeta, float *dz_out, const float *weight_t, float *dx, const float *z_prev,
+                              const float *p_gamma, const float *p_beta, const float *p_mean, const float *p_invstd,
+                              float *p_dgamma, float *p_dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream, int elu)
 {
     if (rows <= 0 || cout <= 0 || cin <= 0 || cin > 256 || !dy_or_dz || !weight_t) return HF_EINVAL;
     const bool from_dy = z != nullptr;
@@ -672,7 +707,7 @@ HF_API int hf_linear_bn_bwd(long long rows, int cout, int cin, const float *dy_o
 #define HF_BWD(N, V, F)                                                                                                 \
     hipLaunchKernelGGL((linear_bwd_kernel<N, V, F>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, cout, cin, ntiles,     \
                        dy_or_dz, z, gamma, beta, mean, invstd, dgamma, dbeta, dz_out, weight_t, dx, z_prev, p_gamma,   \
-                       p_beta, p_mean, p_invstd, partial)
+                       p_beta, p_mean, p_invstd, partial, elu)
 #define HF_BWD_N(N)                                                                                                     \
     case N:                                                                                                             \
         if (vec && from_dy) HF_BWD(N, true, true);                                                                      \
@@ -688,4 +723,23 @@ HF_API int hf_linear_bn_bwd(long long rows, int cout, int cin, const float *dy_o
 #undef HF_BWD
     if (sums) launch_bn_bwd_finalize(cin, nblk, partial, p_dgamma, p_dbeta, st);
     return launch_status();
+}
+
+HF_API int hf_linear_bn_bwd(long long rows, int cout, int cin, const float *dy_or_dz, const float *z, const float *gamma,
+                            const float *beta, const float *mean, const float *invstd, const float *dgamma,
+                            const float *dbeta, float *dz_out, const float *weight_t, float *dx, const float *z_prev,
+                            const float *p_gamma, const float *p_beta, const float *p_mean, const float *p_invstd,
+                            float *p_dgamma, float *p_dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    return linear_bn_bwd_impl(rows, cout, cin, dy_or_dz, z, gamma, beta, mean, invstd, dgamma, dbeta, dz_out, weight_t, dx, z_prev, p_gamma,
+                              p_beta, p_mean, p_invstd, p_dgamma, p_dbeta, workspace, workspace_bytes, stream, 0);
+}
+
+HF_API int hf_linear_elu_bn_bwd(long long rows, int cout, int cin, const float *dz, const float *weight_t, float *dx, const float *z_prev,
+                                const float *p_gamma, const float *p_beta, const float *p_mean, const float *p_invstd, float *p_dgamma,
+                                float *p_dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (!z_prev) return HF_EINVAL;
+    return linear_bn_bwd_impl(rows, cout, cin, dz, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, weight_t, dx, z_prev,
+                              p_gamma, p_beta, p_mean, p_invstd, p_dgamma, p_dbeta, workspace, workspace_bytes, stream, 1);
 }

@@ -127,6 +127,10 @@ __device__ __forceinline__ float ord2f(unsigned o)
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+// tf.nn.elu and its slope (pointfly.py:480-497: the activation of every PointCNN layer, applied BEFORE the batch norm)
+__device__ __forceinline__ float elu_fwd(float x) { return x > 0.0f ? x : expm1f(x); }
+__device__ __forceinline__ float elu_slope(float x) { return x > 0.0f ? 1.0f : expf(x); }
+
 // exclusive prefix sum of one int per thread over a 1024-thread workgroup; `wsum` = 16 ints of LDS
 __device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total)
 {

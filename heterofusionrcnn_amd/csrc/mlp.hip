@@ -80,8 +80,6 @@ __device__ __forceinline__ void reduce_rows(float (&a)[VEC], float (&b)[VEC], in
 // (pointfly.dense / conv2d: linear -> ELU -> batch_normalization, hf/core/pointfly.py:371-497): the statistics, the
 // normalisation and the backward pass then see elu(x), computed on load -- the activation never exists in memory.
 constexpr int kBnRelu = 1, kBnEluIn = 2;
-__device__ __forceinline__ float elu_fwd(float x) { return x > 0.0f ? x : expm1f(x); }
-__device__ __forceinline__ float elu_slope(float x) { return x > 0.0f ? 1.0f : expf(x); }
 
 // partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over the block's rows
 template <int VEC>

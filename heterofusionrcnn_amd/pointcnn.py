@@ -63,6 +63,81 @@ class Dense(nn.Module):
         return self.post(linear_nobias(x, self.linear.weight))
 
 
+class _DenseChainElu(torch.autograd.Function):
+    """Two pf.dense layers (linear -> ELU -> BatchNorm, twice: the lifting of the local coordinates, pointcnn.py:96-99) as one
+    node on the fp32 MFMA kernels.  Forward: each layer's batch statistics come out of its GEMM's accumulators (no statistics
+    pass), the first layer's normalisation is applied while the second GEMM stages its operand (no normalisation pass; the
+    normalised activation is stored once, for the weight gradient).  Backward: the BatchNorm-backward sums of the first layer
+    come out of the input-gradient GEMM of the second (no reduction pass)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, g0, b0, w1, g1, b1, bn0, bn1):
+        L = _lib.lib()
+        rows = x.shape[0]
+        c0, c1 = w0.shape[0], w1.shape[0]
+        dev = x.device
+
+        def layer(inp, w, bn, in_bn, want_act):
+            cout, cin = w.shape
+            nbytes = L.hf_linear_bn_fwd_workspace(cout)
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+            z = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+            mean, invstd = torch.empty((cout,), dtype=torch.float32, device=dev), torch.empty((cout,), dtype=torch.float32, device=dev)
+            act = torch.empty_like(inp) if want_act else None
+            g, b, m, i = in_bn if in_bn is not None else (None, None, None, None)
+            check(L.hf_linear_elu_bn_fwd(rows, cin, cout, ptr(inp), ptr(g), ptr(b), ptr(m), ptr(i), ptr(act), ptr(w), ptr(z), bn.eps,
+                                         bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(mean), ptr(invstd), ptr(ws), nbytes,
+                                         stream_ptr()), "linear_elu_bn_fwd")
+            return z, mean, invstd, act
+
+        w0, w1 = w0.contiguous(), w1.contiguous()
+        z0, m0, i0, _ = layer(x, w0, bn0, None, False)
+        z1, m1, i1, y0 = layer(z0, w1, bn1, (g0, b0, m0, i0), True)
+        out = torch.empty_like(z1)
+        check(L.hf_bn_relu_fwd_eval(rows, c1, ptr(z1), ptr(g1), ptr(b1), ptr(m1), ptr(i1), 2, ptr(out), stream_ptr()), "bn_elu_apply")
+        ctx.save_for_backward(x, z0, m0, i0, y0, z1, m1, i1, w0, g0, b0, w1, g1, b1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .mlp import _splitk_wgrad
+        L = _lib.lib()
+        x, z0, m0, i0, y0, z1, m1, i1, w0, g0, b0, w1, g1, b1 = ctx.saved_tensors
+        rows, c0, c1 = x.shape[0], w0.shape[0], w1.shape[0]
+        dout = dout.contiguous()
+        dz1 = torch.empty_like(z1)
+        dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
+        ws, nbytes = _bn_ws(rows, c1, x.device)
+        check(L.hf_bn_relu_bwd(rows, c1, ptr(z1), ptr(dout), ptr(g1), ptr(b1), ptr(m1), ptr(i1), 2, ptr(dz1), ptr(dg1), ptr(db1), None,
+                               ptr(ws), nbytes, stream_ptr()), "bn_elu_bwd")
+        dy0 = torch.empty_like(z0)
+        dg0, db0 = torch.empty_like(g0), torch.empty_like(b0)
+        nbytes = L.hf_linear_bn_bwd_workspace(c0)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+        w1t = w1.t().contiguous()
+        check(L.hf_linear_elu_bn_bwd(rows, c1, c0, ptr(dz1), ptr(w1t), ptr(dy0), ptr(z0), ptr(g0), ptr(b0), ptr(m0), ptr(i0), ptr(dg0),
+                                     ptr(db0), ptr(ws), nbytes, stream_ptr()), "linear_elu_bn_bwd")
+        dz0 = torch.empty_like(z0)
+        check(L.hf_bn_relu_bwd_dx(rows, c0, ptr(z0), ptr(dy0), ptr(g0), ptr(b0), ptr(m0), ptr(i0), ptr(dg0), ptr(db0), 2, ptr(dz0),
+                                  stream_ptr()), "bn_elu_bwd_dx")
+        dx = dz0 @ w0 if ctx.needs_input_grad[0] else None
+        return dx, _splitk_wgrad(dz0, x), dg0, db0, _splitk_wgrad(dz1, y0), dg1, db1, None, None
+
+
+def dense_chain(d0, d1, x):
+    """d1(d0(x)) for two Dense modules; tall training batches on the device take the one-node MFMA route"""
+    from .mlp import FUSED_FWD_MIN_ROWS
+    rows = x.numel() // x.shape[-1]
+    bn0, bn1 = d0.post.bn, d1.post.bn
+    c0, c1 = d0.linear.out_features, d1.linear.out_features
+    if (x.is_cuda and x.dtype == torch.float32 and bn0.training and bn1.training and d0.post.activation and d1.post.activation
+            and rows >= FUSED_FWD_MIN_ROWS and c0 <= 160 and c1 <= 224 and x.shape[-1] <= 1024):
+        out = _DenseChainElu.apply(x.reshape(rows, x.shape[-1]).contiguous(), d0.linear.weight, bn0.weight, bn0.bias, d1.linear.weight,
+                                   bn1.weight, bn1.bias, bn0, bn1)
+        return out.reshape(*x.shape[:-1], c1)
+    return d1(d0(x))
+
+
 def _bn_mode(bn):
     return (1 if bn.relu else 0) | (2 if bn.elu_in else 0)
 
@@ -404,7 +479,7 @@ class XConv(nn.Module):
         bn1 = self.lift1.post.bn
         gather = self.with_x and fts is not None and _gather_fusable(local, self.lift1.linear.out_features, fts, self.conv.depthwise, inverse)
         if gather:
-            f = self.lift1(self.lift0(local))                 # F_delta alone: the neighbours' features are read in place below
+            f = dense_chain(self.lift0, self.lift1, local)    # F_delta alone: the neighbours' features are read in place below
         elif fts is not None and _fusable(bn1, fts, self.lift1.linear.out_features, self.lift1.linear.out_features + fts.shape[-1]):
             # F_* <- [F_delta, F]: the second lifting layer's BatchNorm writes into the concat, the gather fills the rest
             z = linear_nobias(self.lift0(local), self.lift1.linear.weight)

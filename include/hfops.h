@@ -343,6 +343,20 @@ int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, const fl
                      float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd,
                      void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* The same pass for PointCNN's layer order, pf.dense = linear (no bias) -> ELU -> BatchNorm (pointfly.py:480-497): z is the
+ * pre-activation output, the statistics are those of elu(z), and with in_gamma != NULL x is the previous dense layer's
+ * pre-activation output with a (elu(x) - mean) + beta applied while it is staged (x_act: stored as well). */
+int hf_linear_elu_bn_fwd(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,
+                         const float *in_mean, const float *in_invstd, float *x_act, const float *weight, float *z, float eps,
+                         float momentum, float *running_mean, float *running_var, float *mean, float *invstd, void *workspace,
+                         size_t workspace_bytes, hf_stream_t stream);
+/* ... and its input gradient: dx (rows, cin) = dz (rows, cout) W with the BatchNorm-backward sums of the dense layer BELOW
+ * (p_dgamma = sum dx * xhat, p_dbeta = sum dx, xhat from elu(z_prev)) taken from the accumulators; workspace as
+ * hf_linear_bn_bwd_workspace(cin). */
+int hf_linear_elu_bn_bwd(long long rows, int cout, int cin, const float *dz, const float *weight_t, float *dx, const float *z_prev,
+                         const float *p_gamma, const float *p_beta, const float *p_mean, const float *p_invstd, float *p_dgamma,
+                         float *p_dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 /* The second half of hf_bn_relu_bwd alone: dx from dy, x and ALREADY KNOWN dgamma / dbeta (no reduction pass). */
 int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
                       const float *save_mean, const float *save_invstd, const float *dgamma, const float *dbeta, int relu,

@@ -1679,3 +1679,48 @@ def test_xconv_depthwise_gather_equals_materialised_concat(c0, c1, m):
     # no gradient asked of the table: no inverse needed
     out2 = pc.xconv_depthwise_gather(x, fd, fts.detach(), idx, wd)
     assert torch.equal(out2, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,c", [(3, 64), (3, 128), (24, 32)])
+def test_dense_chain_elu_node_equals_layer_by_layer(cin, c):
+    """pointcnn.dense_chain (two pf.dense layers as one node: statistics from the GEMM accumulators, first normalisation on
+    operand load, first layer's BatchNorm-backward sums from the second layer's input-gradient GEMM) against the same two
+    Dense modules run layer by layer (library / MFMA GEMM, hf_bn_* passes), and both against torch ops in fp64."""
+    from heterofusionrcnn_amd import pointcnn as pc
+    torch.manual_seed(5)
+    rows = 40000
+    d0, d1 = pc.Dense(cin, c).cuda().train(), pc.Dense(c, c).cuda().train()
+    with torch.no_grad():
+        for d in (d0, d1):
+            d.post.bn.weight.uniform_(0.5, 1.5)
+            d.post.bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(8, rows // 8, cin, device="cuda")
+    go = torch.randn(8, rows // 8, c, device="cuda") / rows
+    params = [d0.linear.weight, d0.post.bn.weight, d0.post.bn.bias, d1.linear.weight, d1.post.bn.weight, d1.post.bn.bias]
+    rm = [d.post.bn.running_mean.clone() for d in (d0, d1)]
+    out_a = pc.dense_chain(d0, d1, x)
+    g_a = torch.autograd.grad(out_a, params, go)
+    rm_a = [d.post.bn.running_mean.clone() for d in (d0, d1)]
+    for d, r in zip((d0, d1), rm):
+        d.post.bn.running_mean.copy_(r)
+    out_b = d1(d0(x))
+    g_b = torch.autograd.grad(out_b, params, go)
+    rm_b = [d.post.bn.running_mean.clone() for d in (d0, d1)]
+
+    def ref64():
+        h = x.double().reshape(rows, cin)
+        for d in (d0, d1):
+            e = torch.nn.functional.elu(h @ d.linear.weight.double().t())
+            mu, var = e.mean(0), e.var(0, unbiased=False)
+            h = (e - mu) / torch.sqrt(var + d.post.bn.eps) * d.post.bn.weight.double() + d.post.bn.bias.double()
+        return h.reshape(8, rows // 8, c)
+    out_r = ref64()
+    g_r = torch.autograd.grad(out_r, params, go.double())
+    assert float((out_a.detach() - out_r.detach()).abs().max()) <= 2e-4 and float((out_b.detach() - out_r.detach()).abs().max()) <= 2e-4
+    for a, b, r, name in zip(g_a, g_b, g_r, ("w0", "gamma0", "beta0", "w1", "gamma1", "beta1")):
+        scale = float(r.abs().max())
+        assert float((a - r.float()).abs().max()) <= 2e-3 * scale + 1e-9, (name, float((a - r.float()).abs().max()), scale)
+        assert float((b - r.float()).abs().max()) <= 2e-3 * scale + 1e-9, name
+    for a, b in zip(rm_a, rm_b):
+        assert float((a - b).abs().max()) <= 1e-6
