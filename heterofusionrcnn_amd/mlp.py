@@ -361,7 +361,7 @@ def _shared_mlp_eval(layers, x, pool_k, extra):
         else:
             xin = _bn_apply(cur, *in_bn) if in_bn is not None else cur
             z = torch.addmm(layer.fc.bias, xin, w.t())
-        cur, in_bn = z, (bn.weight, bn.bias, bn.running_mean, torch.rsqrt(bn.running_var + bn.eps))
+        cur, in_bn = z, (bn.weight, bn.bias, bn.running_mean, bn.eval_invstd())
     gamma, beta, mean, invstd = in_bn
     if not pool_k:
         return _bn_apply(cur, gamma, beta, mean, invstd)
@@ -466,6 +466,20 @@ class BatchNormReLU(nn.Module):
         self.bias = nn.Parameter(torch.zeros(num_features))    # beta: 0
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
+        self._eval_invstd = None      # (version of running_var, device, 1/sqrt(running_var + eps)): inference reuses it
+
+    def train(self, mode=True):
+        self._eval_invstd = None      # the training kernels update running_var through its pointer: no version bump
+        return super().train(mode)
+
+    def eval_invstd(self):
+        """1/sqrt(running_var + eps), kept between inference calls (two tiny kernels per layer and batch otherwise: 1800 launches
+        per batch of the two-stage inference); dropped on every train() / eval() switch and when running_var is written"""
+        rv = self.running_var
+        key = (rv._version, rv.device, rv.data_ptr())
+        if self._eval_invstd is None or self._eval_invstd[0] != key:
+            self._eval_invstd = (key, torch.rsqrt(rv + self.eps))
+        return self._eval_invstd[1]
 
     def forward(self, x):
         assert x.dim() == 2 and x.shape[1] == self.num_features
@@ -476,7 +490,7 @@ class BatchNormReLU(nn.Module):
             return _BNReLUTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                       self.momentum, (1 if self.relu else 0) | (2 if self.elu_in else 0))
         y = torch.empty_like(x)
-        invstd = torch.rsqrt(self.running_var + self.eps)
+        invstd = self.eval_invstd()
         check(_lib.lib().hf_bn_relu_fwd_eval(x.shape[0], x.shape[1], ptr(x), ptr(self.weight), ptr(self.bias),
                                              ptr(self.running_mean), ptr(invstd),
                                              (1 if self.relu else 0) | (2 if self.elu_in else 0), ptr(y),
@@ -537,7 +551,7 @@ def linear_bn_relu_maxpool(x, weight, bias, bn, k):
     z = torch.addmm(bias, x, weight.t())
     groups, cout = x.shape[0] // k, weight.shape[0]
     pooled = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
-    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    invstd = bn.eval_invstd()
     check(_lib.lib().hf_bn_relu_maxpool_fwd(groups, k, cout, ptr(z), ptr(bn.weight), ptr(bn.bias), 0, bn.eps, bn.momentum,
                                             None, None, ptr(bn.running_mean), ptr(invstd), ptr(pooled), None, None, 0,
                                             stream_ptr()), "bn_relu_maxpool_fwd")
