@@ -129,3 +129,28 @@ def test_ball_query_variant_and_workspace_argument_checks():
     assert L.hf_farthest_point_sample_variant(5, 0, 1, 64, 8, one, None, one, None) == _lib.HF_EINVAL
     assert L.hf_farthest_point_sample_variant(1, 300, 1, 64, 8, one, None, one, None) == _lib.HF_EINVAL
     assert L.hf_farthest_point_sample_variant(1, 256, 1, 8000, 8, one, None, one, None) == _lib.HF_EINVAL
+
+
+def test_xconv_gather_and_elu_chain_argument_checks():
+    """round-3 entry points: the in-place feature read of the X-Conv and the ELU-order MFMA layers"""
+    from heterofusionrcnn_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(16)
+    ok = (2, 100, 50, 8, 64, 32, 1)                                   # b, n_src, rows_per_cloud, k, c0, c1, m
+    assert L.hf_xconv_depthwise_gather(2, 100, 50, 8, 48, 32, 1, one, one, one, one, one, one, None) == _lib.HF_EINVAL     # c0 % 64
+    assert L.hf_xconv_depthwise_gather(2, 100, 50, 8, 64, 0, 1, one, one, one, one, one, one, None) == _lib.HF_EINVAL      # nothing to gather
+    assert L.hf_xconv_depthwise_gather(*ok, one, one, None, one, one, one, None) == _lib.HF_EINVAL                          # no feature table
+    assert L.hf_xconv_depthwise_gather(0, 100, 50, 8, 64, 32, 1, one, one, one, one, one, one, None) == _lib.HF_OK          # empty batch
+    assert L.hf_xconv_depthwise_gather_grad_workspace(2, 50, 8, 32) == 4 * 2 * 50 * 8 * 32
+    assert L.hf_xconv_depthwise_gather_grad_workspace(0, 50, 8, 32) == 0
+    grads_none = (None, None, None, None)
+    assert L.hf_xconv_depthwise_gather_grad(*ok, one, one, one, one, one, one, one, one, *grads_none, None, 0, None) == _lib.HF_EINVAL
+    # a gradient of the feature table needs the inverse neighbour table; a workspace must be large enough
+    assert L.hf_xconv_depthwise_gather_grad(*ok, one, one, one, one, one, one, None, None, None, None, one, None, None, 0,
+                                            None) == _lib.HF_EINVAL
+    assert L.hf_xconv_depthwise_gather_grad(*ok, one, one, one, one, one, one, one, one, None, None, one, None, one, 64,
+                                            None) == _lib.HF_EWORKSPACE
+    # ELU-order input gradient: the layer below is what it exists for
+    assert L.hf_linear_elu_bn_bwd(1024, 64, 64, one, one, one, None, one, one, one, one, one, one, one, 1 << 20, None) == _lib.HF_EINVAL
+    assert L.hf_linear_elu_bn_fwd(1024, 3, 512, one, None, None, None, None, None, one, one, 1e-3, 0.01, None, None, one, one, one, 1 << 20,
+                                  None) == _lib.HF_EINVAL                                                                       # cout <= 256
