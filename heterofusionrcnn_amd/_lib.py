@@ -81,6 +81,11 @@ _SIGNATURES = {
     "hf_linear_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 18 + [_vp, _sz, _vp],
     "hf_linear_elu_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_linear_elu_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 10 + [_vp, _sz, _vp],
+    "hf_lift_elu_bn_fwd_workspace": [_i, _i],
+    "hf_lift_elu_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
+                           _vp, _sz, _vp],
+    "hf_lift_elu_bn_bwd_workspace": [ctypes.c_longlong, _i, _i],
+    "hf_lift_elu_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 12 + [_vp, _sz, _vp],
     "hf_project_gather": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_project_gather_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_fuse_concat": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -119,6 +124,8 @@ _RESTYPES = {
     "hf_linear_bn_fwd_workspace": _sz,
     "hf_linear_bn_bwd_workspace": _sz,
     "hf_xconv_depthwise_gather_grad_workspace": _sz,
+    "hf_lift_elu_bn_fwd_workspace": _sz,
+    "hf_lift_elu_bn_bwd_workspace": _sz,
     "hf_version": ctypes.c_char_p,
     "hf_strerror": ctypes.c_char_p,
 }

@@ -542,6 +542,414 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The lifting chain of an X-Conv (pointcnn.py:96-99): two pf.dense layers on the K local coordinates of every point,
+//   y0 = BN0(elu(W0 x)),  x (rows, 3);      z1 = y0 W1^T,  out = BN1(elu(z1)).
+// The first layer has THREE input channels: its output (rows x C0, 268 MB at a million rows) is cheaper to recompute from x
+// wherever it is needed than to write once and read four times.  Every kernel below forms z0 the same way (lift_z), so the
+// forward statistics, the operand of the second GEMM, the weight gradient and both backward passes see the same bits.
+// ------------------------------------------------------------------------------------------
+constexpr int kLiftMaxC = 256;
+struct LiftTab {
+    float wx[kLiftMaxC], wy[kLiftMaxC], wz[kLiftMaxC], a[kLiftMaxC], mu[kLiftMaxC], be[kLiftMaxC], is[kLiftMaxC];
+};
+
+__device__ __forceinline__ void lift_tab_load(LiftTab &T, int c, const float *__restrict__ w0, const float *__restrict__ gamma,
+                                              const float *__restrict__ beta, const float *__restrict__ mean,
+                                              const float *__restrict__ invstd)
+{
+    for (int k = threadIdx.x; k < c; k += blockDim.x) {
+        T.wx[k] = w0[3 * k];
+        T.wy[k] = w0[3 * k + 1];
+        T.wz[k] = w0[3 * k + 2];
+        T.a[k] = gamma[k] * invstd[k];
+        T.mu[k] = mean[k];
+        T.be[k] = beta[k];
+        T.is[k] = invstd[k];
+    }
+}
+__device__ __forceinline__ float lift_z(float wx, float wy, float wz, float x0, float x1, float x2) { return (x0 * wx + x1 * wy) + x2 * wz; }
+__device__ __forceinline__ float lift_y(const LiftTab &T, int k, float x0, float x1, float x2)
+{
+    return T.a[k] * (elu_fwd(lift_z(T.wx[k], T.wy[k], T.wz[k], x0, x1, x2)) - T.mu[k]) + T.be[k];
+}
+
+// batch statistics of elu(W0 x): a lane owns a channel, the waves of a block walk a chunk of rows (x is wave-uniform)
+__global__ __launch_bounds__(256) void lift_stats_kernel(long long rows, int c, long long rows_per_block,
+                                                         const float *__restrict__ x3, const float *__restrict__ w0,
+                                                         float *__restrict__ partial)
+{
+    __shared__ float red[4][64][2];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int ch = blockIdx.y * 64 + lane;
+    const bool live = ch < c;
+    const float wx = live ? w0[3 * ch] : 0.f, wy = live ? w0[3 * ch + 1] : 0.f, wz = live ? w0[3 * ch + 2] : 0.f;
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s = 0.f, q = 0.f;
+    for (long long r = r0 + wave; r < r1; r += 4) {
+        const float e = elu_fwd(lift_z(wx, wy, wz, x3[3 * r], x3[3 * r + 1], x3[3 * r + 2]));
+        s += e;
+        q += e * e;
+    }
+    red[wave][lane][0] = s;
+    red[wave][lane][1] = q;
+    __syncthreads();
+    if (wave == 0 && live) {
+        float a = red[0][lane][0], b = red[0][lane][1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { a += red[w][lane][0]; b += red[w][lane][1]; }
+        partial[static_cast<size_t>(ch) * kBnMaxBlocks + blockIdx.x] = a;
+        partial[static_cast<size_t>(c + ch) * kBnMaxBlocks + blockIdx.x] = b;
+    }
+}
+
+// z1 = y0 W1^T with y0 generated from x while the operand is staged; statistics of elu(z1) from the accumulators
+template <int NT>
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2))) void lift_linear_fwd_kernel(
+    long long rows, int c0, int cout, long long ntiles, const float *__restrict__ x3, const float *__restrict__ w0,
+    const float *__restrict__ gamma0, const float *__restrict__ beta0, const float *__restrict__ mean0,
+    const float *__restrict__ invstd0, const float *__restrict__ W, float *__restrict__ Z, float *__restrict__ partial)
+{
+    __shared__ float As[kFwdRows * kFwdLS];
+    __shared__ float Bs[NT * 32 * kFwdLS];
+    __shared__ float red[4][NT * 32][2];
+    __shared__ LiftTab T;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    lift_tab_load(T, c0, w0, gamma0, beta0, mean0, invstd0);
+    __syncthreads();
+
+    const int k4 = (t & 7) * 4, srow = t >> 3;
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+    float xr[4][3], xn[4][3];
+    float4 br[NT];
+    auto fetch_x = [&](long long r0, float (&dst)[4][3]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long long row = r0 + srow + 32 * p;
+            const bool ok = row < rows;
+            const float *px = x3 + (ok ? row : 0) * 3;
+            const float a = px[0], b = px[1], c = px[2];
+            dst[p][0] = ok ? a : 0.f; dst[p][1] = ok ? b : 0.f; dst[p][2] = ok ? c : 0.f;
+        }
+    };
+    auto fetch_b = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < NT; ++p) br[p] = load4_guarded<true>(W, srow + 32 * p, cout, kc + k4, c0);
+    };
+    if (blockIdx.x < ntiles) { fetch_x(static_cast<long long>(blockIdx.x) * kFwdRows, xr); fetch_b(0); }
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = tile * kFwdRows;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
+        for (int kc = 0; kc < c0; kc += kFwdKC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const bool rin = row0 + srow + 32 * p < rows;
+                const int k = kc + k4;
+                float4 v;
+                v.x = (rin && k < c0) ? lift_y(T, k, xr[p][0], xr[p][1], xr[p][2]) : 0.f;
+                v.y = (rin && k + 1 < c0) ? lift_y(T, k + 1, xr[p][0], xr[p][1], xr[p][2]) : 0.f;
+                v.z = (rin && k + 2 < c0) ? lift_y(T, k + 2, xr[p][0], xr[p][1], xr[p][2]) : 0.f;
+                v.w = (rin && k + 3 < c0) ? lift_y(T, k + 3, xr[p][0], xr[p][1], xr[p][2]) : 0.f;
+                *reinterpret_cast<float4 *>(&As[(srow + 32 * p) * kFwdLS + k4]) = v;
+            }
+#pragma unroll
+            for (int p = 0; p < NT; ++p) *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kFwdLS + k4]) = br[p];
+            __syncthreads();
+            if (kc + kFwdKC < c0) fetch_b(kc + kFwdKC);
+            else if (tile + gridDim.x < ntiles) { fetch_x((tile + gridDim.x) * kFwdRows, xn); fetch_b(0); }
+            const float *ap = As + (32 * wave + (lane & 31)) * kFwdLS + (lane >> 5);
+            const float *bp = Bs + (lane & 31) * kFwdLS + (lane >> 5);
+#pragma unroll 4
+            for (int s = 0; s < kFwdKC / 2; ++s) {
+                const float a = ap[2 * s];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[nt * 32 * kFwdLS + 2 * s], acc[nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xr[p][d] = xn[p][d];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = nt * 32 + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const long long row = row0 + 32 * wave + 8 * (g >> 2) + 4 * (lane >> 5) + (g & 3);
+                const float v = acc[nt][g];
+                if (col < cout && row < rows) {
+                    Z[row * cout + col] = v;
+                    const float sv = elu_fwd(v);
+                    s1[nt] += sv;
+                    s2[nt] += sv * sv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
+        if (lane < 32) {
+            red[wave][nt * 32 + lane][0] = s1[nt];
+            red[wave][nt * 32 + lane][1] = s2[nt];
+        }
+    }
+    __syncthreads();
+    for (int col = t; col < cout; col += kGemmThreads) {
+        float a = red[0][col][0], b = red[0][col][1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { a += red[w][col][0]; b += red[w][col][1]; }
+        partial[static_cast<size_t>(col) * kBnMaxBlocks + blockIdx.x] = a;
+        partial[static_cast<size_t>(cout + col) * kBnMaxBlocks + blockIdx.x] = b;
+    }
+}
+
+// dW1 partial tiles = dz1^T y0 with y0 generated from x while it is staged (the wgrad_kernel above with its X operand rebuilt)
+template <int WM, int WN>
+__global__ __launch_bounds__(kGemmThreads) void lift_wgrad_kernel(long long rows, int cout, int c0, int mtiles,
+                                                                  long long rows_per_chunk, const float *__restrict__ G,
+                                                                  const float *__restrict__ x3, const float *__restrict__ w0,
+                                                                  const float *__restrict__ gamma0, const float *__restrict__ beta0,
+                                                                  const float *__restrict__ mean0, const float *__restrict__ invstd0,
+                                                                  float *__restrict__ partial)
+{
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int GS = TM + 32, XS = TN + 32;
+    constexpr int GC4 = TM / 4, XC4 = TN / 4;
+    constexpr int GPASS = kGemmRowsPerStage * GC4 / kGemmThreads, XPASS = kGemmRowsPerStage * XC4 / kGemmThreads;
+    constexpr int GROWS = kGemmThreads / GC4, XROWS = kGemmThreads / XC4;
+    __shared__ float Gs[kGemmRowsPerStage * GS];
+    __shared__ float Xs[kGemmRowsPerStage * XS];
+    __shared__ LiftTab T;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile_m = blockIdx.x % mtiles, tile_n = blockIdx.x / mtiles;
+    const long long r0 = blockIdx.y * rows_per_chunk;
+    const long long r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    lift_tab_load(T, c0, w0, gamma0, beta0, mean0, invstd0);
+    __syncthreads();
+
+    const int gcol = tile_m * TM + (t % GC4) * 4, grow = t / GC4;
+    const int xcol = tile_n * TN + (t % XC4) * 4, xrow = t / XC4;
+    const bool vec = cout % 4 == 0 && reinterpret_cast<uintptr_t>(G) % 16 == 0;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+    float4 gr[GPASS];
+    float xr[XPASS][3];
+    auto fetch = [&](long long rt) {
+#pragma unroll
+        for (int p = 0; p < GPASS; ++p)
+            gr[p] = vec ? load4_guarded<true>(G, rt + grow + p * GROWS, r1, gcol, cout) : load4_guarded<false>(G, rt + grow + p * GROWS, r1, gcol, cout);
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const long long row = rt + xrow + p * XROWS;
+            const bool ok = row < r1;
+            const float *px = x3 + (ok ? row : 0) * 3;
+            const float a = px[0], b = px[1], c = px[2];
+            xr[p][0] = ok ? a : 0.f; xr[p][1] = ok ? b : 0.f; xr[p][2] = ok ? c : 0.f;
+        }
+    };
+    fetch(r0);
+    for (long long rt = r0; rt < r1; rt += kGemmRowsPerStage) {
+#pragma unroll
+        for (int p = 0; p < GPASS; ++p)
+            *reinterpret_cast<float4 *>(&Gs[(grow + p * GROWS) * GS + (t % GC4) * 4]) = gr[p];
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+            const bool rin = rt + xrow + p * XROWS < r1;
+            float4 v;
+            v.x = (rin && xcol < c0) ? lift_y(T, xcol, xr[p][0], xr[p][1], xr[p][2]) : 0.f;
+            v.y = (rin && xcol + 1 < c0) ? lift_y(T, xcol + 1, xr[p][0], xr[p][1], xr[p][2]) : 0.f;
+            v.z = (rin && xcol + 2 < c0) ? lift_y(T, xcol + 2, xr[p][0], xr[p][1], xr[p][2]) : 0.f;
+            v.w = (rin && xcol + 3 < c0) ? lift_y(T, xcol + 3, xr[p][0], xr[p][1], xr[p][2]) : 0.f;
+            *reinterpret_cast<float4 *>(&Xs[(xrow + p * XROWS) * XS + (t % XC4) * 4]) = v;
+        }
+        __syncthreads();
+        if (rt + kGemmRowsPerStage < r1) fetch(rt + kGemmRowsPerStage);
+        const float *ga = Gs + (lane >> 5) * GS + wm * 32 * WM + (lane & 31);
+        const float *xb = Xs + (lane >> 5) * XS + wn * 32 * WN + (lane & 31);
+        float a[2][WM], b[2][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[0][i] = ga[i * 32];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[0][j] = xb[j * 32];
+#pragma unroll
+        for (int s = 0; s < kGemmRowsPerStage / 2; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < kGemmRowsPerStage / 2) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[nxt][i] = ga[2 * (s + 1) * GS + i * 32];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[nxt][j] = xb[2 * (s + 1) * XS + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float *out = partial + static_cast<size_t>(blockIdx.y) * cout * c0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int k = tile_n * TN + wn * 32 * WN + j * 32 + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int n = tile_m * TM + wm * 32 * WM + i * 32 + 8 * (g >> 2) + 4 * (lane >> 5) + (g & 3);
+                if (n < cout && k < c0) out[static_cast<size_t>(n) * c0 + k] = acc[i][j][g];
+            }
+        }
+}
+
+// dy0 = dz1 W1 is formed in the accumulators and never written.  PASS 0: the BatchNorm-backward sums of the first layer
+// (sum dy0, sum dy0 * xhat0) -> partial[2][c0][blocks].  PASS 1 (dgamma0 / dbeta0 known): dz0 = a0 (dy0 - dbeta0/R - xhat0 dgamma0/R)
+// * elu'(z0) and the first layer's weight gradient dW0[c][d] = sum_r dz0[r][c] x[r][d] -> partial[3][c0][blocks].
+// z0 and xhat0 are rebuilt from x in the epilogue (16 rows per lane).
+template <int NT, int PASS>
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2))) void lift_linear_bwd_kernel(
+    long long rows, int kdim, int c0, long long ntiles, const float *__restrict__ DZ, const float *__restrict__ WT,
+    const float *__restrict__ x3, const float *__restrict__ w0, const float *__restrict__ gamma0, const float *__restrict__ mean0,
+    const float *__restrict__ invstd0, const float *__restrict__ dgamma0, const float *__restrict__ dbeta0,
+    float *__restrict__ partial)
+{
+    constexpr int NV = PASS == 0 ? 2 : 3;
+    __shared__ float As[kFwdRows * kFwdLS];
+    __shared__ float Bs[NT * 32 * kFwdLS];
+    __shared__ float red[4][NT * 32][NV];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // constants of this lane's output columns (channels of the first layer)
+    float wx[NT], wy[NT], wz[NT], pa[NT], pmu[NT], pis[NT], c1[NT], c2[NT], acc_s[NT][NV];
+    const float inv_r = 1.0f / static_cast<float>(rows);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 32 + (lane & 31);
+        const bool ok = col < c0;
+        wx[nt] = ok ? w0[3 * col] : 0.f; wy[nt] = ok ? w0[3 * col + 1] : 0.f; wz[nt] = ok ? w0[3 * col + 2] : 0.f;
+        pmu[nt] = ok ? mean0[col] : 0.f; pis[nt] = ok ? invstd0[col] : 0.f;
+        pa[nt] = (PASS == 1 && ok) ? gamma0[col] * invstd0[col] : 0.f;
+        c1[nt] = (PASS == 1 && ok) ? dbeta0[col] * inv_r : 0.f;
+        c2[nt] = (PASS == 1 && ok) ? dgamma0[col] * inv_r : 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc_s[nt][v] = 0.f;
+    }
+    const bool vec = kdim % 4 == 0 && reinterpret_cast<uintptr_t>(DZ) % 16 == 0 && reinterpret_cast<uintptr_t>(WT) % 16 == 0;
+    const int k4 = (t & 7) * 4, srow = t >> 3;
+    float4 ar[4], br[NT];
+    auto fetch = [&](long long r0, int kc) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            ar[p] = vec ? load4_guarded<true>(DZ, r0 + srow + 32 * p, rows, kc + k4, kdim) : load4_guarded<false>(DZ, r0 + srow + 32 * p, rows, kc + k4, kdim);
+#pragma unroll
+        for (int p = 0; p < NT; ++p)
+            br[p] = vec ? load4_guarded<true>(WT, srow + 32 * p, c0, kc + k4, kdim) : load4_guarded<false>(WT, srow + 32 * p, c0, kc + k4, kdim);
+    };
+    if (blockIdx.x < ntiles) fetch(static_cast<long long>(blockIdx.x) * kFwdRows, 0);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = tile * kFwdRows;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
+        for (int kc = 0; kc < kdim; kc += kFwdKC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<float4 *>(&As[(srow + 32 * p) * kFwdLS + k4]) = ar[p];
+#pragma unroll
+            for (int p = 0; p < NT; ++p) *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kFwdLS + k4]) = br[p];
+            __syncthreads();
+            if (kc + kFwdKC < kdim) fetch(row0, kc + kFwdKC);
+            else if (tile + gridDim.x < ntiles) fetch((tile + gridDim.x) * kFwdRows, 0);
+            const float *ap = As + (32 * wave + (lane & 31)) * kFwdLS + (lane >> 5);
+            const float *bp = Bs + (lane & 31) * kFwdLS + (lane >> 5);
+#pragma unroll 4
+            for (int s = 0; s < kFwdKC / 2; ++s) {
+                const float a = ap[2 * s];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[nt * 32 * kFwdLS + 2 * s], acc[nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const long long row = row0 + 32 * wave + 8 * (g >> 2) + 4 * (lane >> 5) + (g & 3);
+            if (row >= rows) continue;
+            const float x0 = x3[3 * row], x1 = x3[3 * row + 1], x2 = x3[3 * row + 2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt * 32 + (lane & 31) >= c0) continue;
+                const float v = acc[nt][g];
+                const float z0 = lift_z(wx[nt], wy[nt], wz[nt], x0, x1, x2);
+                const float xhat = (elu_fwd(z0) - pmu[nt]) * pis[nt];
+                if (PASS == 0) {
+                    acc_s[nt][0] += v;
+                    acc_s[nt][1] += v * xhat;
+                } else {
+                    const float dz0 = pa[nt] * (v - c1[nt] - xhat * c2[nt]) * elu_slope(z0);
+                    acc_s[nt][0] += dz0 * x0;
+                    acc_s[nt][1] += dz0 * x1;
+                    acc_s[nt][NV - 1] += dz0 * x2;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            acc_s[nt][v] += __shfl_xor(acc_s[nt][v], 32);
+            if (lane < 32) red[wave][nt * 32 + lane][v] = acc_s[nt][v];
+        }
+    __syncthreads();
+    for (int col = t; col < c0; col += kGemmThreads) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float a = red[0][col][v];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) a += red[w][col][v];
+            partial[(static_cast<size_t>(v) * c0 + col) * kBnMaxBlocks + blockIdx.x] = a;
+        }
+    }
+}
+
+// out[row] = sum over blocks of partial[row][blk] (fp64 tree, a workgroup per row)
+__global__ __launch_bounds__(256) void partial_rows_sum_kernel(int nblk, const float *__restrict__ partial, float *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    double a = 0.0;
+    const float *p = partial + static_cast<size_t>(blockIdx.x) * kBnMaxBlocks;
+    for (int i = t; i < nblk; i += 256) a += static_cast<double>(p[i]);
+    red[t] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) out[blockIdx.x] = static_cast<float>(red[0]);
+}
+
 struct WgradPlan {
     int wm, wn, mtiles, ntiles, chunks;
     long long rows_per_chunk;
@@ -742,4 +1150,102 @@ HF_API int hf_linear_elu_bn_bwd(long long rows, int cout, int cin, const float *
     if (!z_prev) return HF_EINVAL;
     return linear_bn_bwd_impl(rows, cout, cin, dz, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, weight_t, dx, z_prev,
                               p_gamma, p_beta, p_mean, p_invstd, p_dgamma, p_dbeta, workspace, workspace_bytes, stream, 1);
+}
+
+HF_API size_t hf_lift_elu_bn_fwd_workspace(int c0, int c1)
+{
+    if (c0 <= 0 || c1 <= 0) return 0;
+    return sizeof(float) * 2 * static_cast<size_t>(c0 > c1 ? c0 : c1) * kBnMaxBlocks;
+}
+
+HF_API int hf_lift_elu_bn_fwd(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                              float eps0, float momentum0, float *running_mean0, float *running_var0, float *mean0, float *invstd0,
+                              const float *w1, float *z1, float eps1, float momentum1, float *running_mean1, float *running_var1,
+                              float *mean1, float *invstd1, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows <= 0 || c0 <= 0 || c0 > kLiftMaxC || c0 % 4 != 0 || c1 <= 0 || c1 > 256 || !x3 || !w0 || !gamma0 || !beta0 || !mean0 ||
+        !invstd0 || !w1 || !z1 || !mean1 || !invstd1 || reinterpret_cast<uintptr_t>(w1) % 16 != 0)
+        return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_lift_elu_bn_fwd_workspace(c0, c1)) return HF_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    long long nblk0 = (rows + 255) / 256;
+    if (nblk0 > kBnMaxBlocks) nblk0 = kBnMaxBlocks;
+    const long long rpb = (rows + nblk0 - 1) / nblk0;
+    nblk0 = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(lift_stats_kernel, dim3(static_cast<unsigned>(nblk0), div_up(c0, 64)), dim3(256), 0, st, rows, c0, rpb, x3, w0,
+                       partial);
+    launch_bn_stats_finalize(rows, c0, static_cast<int>(nblk0), partial, eps0, momentum0, running_mean0, running_var0, mean0, invstd0, st);
+    const long long ntiles = (rows + kFwdRows - 1) / kFwdRows;
+    const int nt = div_up(c1, 32);
+    const int nblk = resident_grid(nt, ntiles);
+#define HF_LIFT_FWD(N)                                                                                                  \
+    case N:                                                                                                             \
+        hipLaunchKernelGGL((lift_linear_fwd_kernel<N>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, c0, c1, ntiles, x3, w0,  \
+                           gamma0, beta0, mean0, invstd0, w1, z1, partial);                                             \
+        break
+    switch (nt) {
+        HF_LIFT_FWD(1); HF_LIFT_FWD(2); HF_LIFT_FWD(3); HF_LIFT_FWD(4); HF_LIFT_FWD(5); HF_LIFT_FWD(6); HF_LIFT_FWD(7); HF_LIFT_FWD(8);
+        default: return HF_EINVAL;
+    }
+#undef HF_LIFT_FWD
+    launch_bn_stats_finalize(rows, c1, nblk, partial, eps1, momentum1, running_mean1, running_var1, mean1, invstd1, st);
+    return launch_status();
+}
+
+HF_API size_t hf_lift_elu_bn_bwd_workspace(long long rows, int c0, int c1)
+{
+    if (rows <= 0 || c0 <= 0 || c1 <= 0) return 0;
+    return hf_linear_wgrad_workspace(rows, c1, c0) + sizeof(float) * 3 * static_cast<size_t>(c0) * kBnMaxBlocks;
+}
+
+HF_API int hf_lift_elu_bn_bwd(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                              const float *mean0, const float *invstd0, const float *dz1, const float *w1_t, float *grad_w0_t,
+                              float *grad_w1, float *dgamma0, float *dbeta0, void *workspace, size_t workspace_bytes,
+                              hf_stream_t stream)
+{
+    if (rows <= 0 || c0 <= 0 || c0 > 160 || c0 % 4 != 0 || c1 <= 0 || c1 > 256 || !x3 || !w0 || !gamma0 || !beta0 || !mean0 || !invstd0 ||
+        !dz1 || !w1_t || !grad_w0_t || !grad_w1 || !dgamma0 || !dbeta0)
+        return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_lift_elu_bn_bwd_workspace(rows, c0, c1)) return HF_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    // dW1 = dz1^T y0
+    const WgradPlan p = wgrad_plan(rows, c1, c0);
+    if (p.chunks > 65535) return HF_EINVAL;
+    float *wpartial = static_cast<float *>(workspace);
+    float *spartial = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + hf_linear_wgrad_workspace(rows, c1, c0));
+    const dim3 wgrid(p.mtiles * p.ntiles, p.chunks);
+#define HF_LIFT_WG(M, N)                                                                                                \
+    hipLaunchKernelGGL((lift_wgrad_kernel<M, N>), wgrid, dim3(kGemmThreads), 0, st, rows, c1, c0, p.mtiles, p.rows_per_chunk, \
+                       dz1, x3, w0, gamma0, beta0, mean0, invstd0, wpartial)
+    if (p.wm == 2 && p.wn == 2) HF_LIFT_WG(2, 2);
+    else if (p.wm == 2) HF_LIFT_WG(2, 1);
+    else if (p.wn == 2) HF_LIFT_WG(1, 2);
+    else HF_LIFT_WG(1, 1);
+#undef HF_LIFT_WG
+    const int total = c1 * c0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(total, 64)), dim3(64 * kWredGroups), 0, st, total, p.chunks, wpartial, grad_w1);
+    // the first layer's BatchNorm-backward sums, then its weight gradient: dy0 = dz1 W1 rebuilt in the accumulators both times
+    const long long ntiles = (rows + kFwdRows - 1) / kFwdRows;
+    const int nt = div_up(c0, 32);
+    const int nblk = resident_grid(nt, ntiles);
+#define HF_LIFT_BWD(N, P)                                                                                               \
+    hipLaunchKernelGGL((lift_linear_bwd_kernel<N, P>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, c1, c0, ntiles, dz1, w1_t, x3, w0, \
+                       gamma0, mean0, invstd0, dgamma0, dbeta0, spartial)
+#define HF_LIFT_BWD_N(P)                                                                                                \
+    switch (nt) {                                                                                                       \
+    case 1: HF_LIFT_BWD(1, P); break;                                                                                   \
+    case 2: HF_LIFT_BWD(2, P); break;                                                                                   \
+    case 3: HF_LIFT_BWD(3, P); break;                                                                                   \
+    case 4: HF_LIFT_BWD(4, P); break;                                                                                   \
+    case 5: HF_LIFT_BWD(5, P); break;                                                                                   \
+    default: return HF_EINVAL;                                                                                          \
+    }
+    HF_LIFT_BWD_N(0)
+    launch_bn_bwd_finalize(c0, nblk, spartial, dgamma0, dbeta0, st);
+    HF_LIFT_BWD_N(1)
+#undef HF_LIFT_BWD_N
+#undef HF_LIFT_BWD
+    hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(3 * c0), dim3(256), 0, st, nblk, spartial, grad_w0_t);
+    return launch_status();
 }

@@ -124,6 +124,52 @@ class _DenseChainElu(torch.autograd.Function):
         return dx, _splitk_wgrad(dz0, x), dg0, db0, _splitk_wgrad(dz1, y0), dg1, db1, None, None
 
 
+class _LiftChain(torch.autograd.Function):
+    """The lifting chain on a THREE-channel input (the local coordinates, pointcnn.py:96-99) without its first layer's output in
+    memory: the statistics of elu(W0 x) from one pass over x, y0 = BN0(elu(W0 x)) rebuilt from x inside the second GEMM's operand
+    staging, inside the weight-gradient GEMM and inside the two backward passes (hf_lift_elu_bn_fwd / _bwd).  Of the chain's
+    rows x C tensors only z1 (pre-activation of the second layer), the output and dz1 are ever written."""
+
+    @staticmethod
+    def forward(ctx, x, w0, g0, b0, w1, g1, b1, bn0, bn1):
+        L = _lib.lib()
+        rows, c0, c1, dev = x.shape[0], w0.shape[0], w1.shape[0], x.device
+        w0, w1 = w0.contiguous(), w1.contiguous()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        m0, i0, m1, i1, z1 = new(c0), new(c0), new(c1), new(c1), new(rows, c1)
+        nbytes = L.hf_lift_elu_bn_fwd_workspace(c0, c1)
+        ws = new(nbytes // 4)
+        check(L.hf_lift_elu_bn_fwd(rows, c0, c1, ptr(x), ptr(w0), ptr(g0), ptr(b0), bn0.eps, bn0.momentum, ptr(bn0.running_mean),
+                                   ptr(bn0.running_var), ptr(m0), ptr(i0), ptr(w1), ptr(z1), bn1.eps, bn1.momentum,
+                                   ptr(bn1.running_mean), ptr(bn1.running_var), ptr(m1), ptr(i1), ptr(ws), nbytes, stream_ptr()),
+              "lift_elu_bn_fwd")
+        out = torch.empty_like(z1)
+        check(L.hf_bn_relu_fwd_eval(rows, c1, ptr(z1), ptr(g1), ptr(b1), ptr(m1), ptr(i1), 2, ptr(out), stream_ptr()), "bn_elu_apply")
+        ctx.save_for_backward(x, m0, i0, z1, m1, i1, w0, g0, b0, w1, g1, b1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x, m0, i0, z1, m1, i1, w0, g0, b0, w1, g1, b1 = ctx.saved_tensors
+        rows, c0, c1, dev = x.shape[0], w0.shape[0], w1.shape[0], x.device
+        dout = dout.contiguous()
+        dz1 = torch.empty_like(z1)
+        dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
+        ws, nbytes = _bn_ws(rows, c1, dev)
+        check(L.hf_bn_relu_bwd(rows, c1, ptr(z1), ptr(dout), ptr(g1), ptr(b1), ptr(m1), ptr(i1), 2, ptr(dz1), ptr(dg1), ptr(db1), None,
+                               ptr(ws), nbytes, stream_ptr()), "bn_elu_bwd")
+        dw0_t = torch.empty((3, c0), dtype=torch.float32, device=dev)
+        dw1 = torch.empty_like(w1)
+        dg0, db0 = torch.empty_like(g0), torch.empty_like(b0)
+        nbytes = L.hf_lift_elu_bn_bwd_workspace(rows, c0, c1)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+        w1t = w1.t().contiguous()
+        check(L.hf_lift_elu_bn_bwd(rows, c0, c1, ptr(x), ptr(w0), ptr(g0), ptr(b0), ptr(m0), ptr(i0), ptr(dz1), ptr(w1t), ptr(dw0_t),
+                                   ptr(dw1), ptr(dg0), ptr(db0), ptr(ws), nbytes, stream_ptr()), "lift_elu_bn_bwd")
+        return None, dw0_t.t(), dg0, db0, dw1, dg1, db1, None, None
+
+
 def dense_chain(d0, d1, x):
     """d1(d0(x)) for two Dense modules; tall training batches on the device take the one-node MFMA route"""
     from .mlp import FUSED_FWD_MIN_ROWS
@@ -132,6 +178,10 @@ def dense_chain(d0, d1, x):
     c0, c1 = d0.linear.out_features, d1.linear.out_features
     if (x.is_cuda and x.dtype == torch.float32 and bn0.training and bn1.training and d0.post.activation and d1.post.activation
             and rows >= FUSED_FWD_MIN_ROWS and c0 <= 160 and c1 <= 224 and x.shape[-1] <= 1024):
+        if x.shape[-1] == 3 and c0 % 4 == 0 and not x.requires_grad:
+            out = _LiftChain.apply(x.reshape(rows, 3).contiguous(), d0.linear.weight, bn0.weight, bn0.bias, d1.linear.weight, bn1.weight,
+                                   bn1.bias, bn0, bn1)
+            return out.reshape(*x.shape[:-1], c1)
         out = _DenseChainElu.apply(x.reshape(rows, x.shape[-1]).contiguous(), d0.linear.weight, bn0.weight, bn0.bias, d1.linear.weight,
                                    bn1.weight, bn1.bias, bn0, bn1)
         return out.reshape(*x.shape[:-1], c1)

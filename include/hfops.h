@@ -357,6 +357,23 @@ int hf_linear_elu_bn_bwd(long long rows, int cout, int cin, const float *dz, con
                          const float *p_gamma, const float *p_beta, const float *p_mean, const float *p_invstd, float *p_dgamma,
                          float *p_dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* The lifting chain of an X-Conv (pointcnn.py:96-99), two pf.dense layers on the local coordinates: x3 (rows, 3) ->
+ * y0 = BN0(elu(x3 W0^T)) (c0 channels) -> z1 = y0 W1^T (c1 channels; the caller normalises elu(z1) with mean1 / invstd1).
+ * The first layer's output is never stored: its statistics come from one pass over x3, and the second GEMM rebuilds y0 from x3
+ * while it stages its operand.  w0 (c0, 3), w1 (c1, c0); batch statistics and running estimates of both layers are produced.
+ * hf_lift_elu_bn_bwd: from dz1 (rows, c1) = the gradient w.r.t. z1: grad_w1 (c1, c0), dgamma0 / dbeta0 (c0), and grad_w0_t (3, c0) =
+ * the TRANSPOSE of the first layer's weight gradient; dy0 = dz1 W1 (w1_t = W1^T as (c0, c1)) is rebuilt in the accumulators of
+ * two passes and never written.  c0 <= 160 (a multiple of 4), c1 <= 256. */
+size_t hf_lift_elu_bn_fwd_workspace(int c0, int c1);
+int hf_lift_elu_bn_fwd(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                       float eps0, float momentum0, float *running_mean0, float *running_var0, float *mean0, float *invstd0,
+                       const float *w1, float *z1, float eps1, float momentum1, float *running_mean1, float *running_var1,
+                       float *mean1, float *invstd1, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+size_t hf_lift_elu_bn_bwd_workspace(long long rows, int c0, int c1);
+int hf_lift_elu_bn_bwd(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                       const float *mean0, const float *invstd0, const float *dz1, const float *w1_t, float *grad_w0_t,
+                       float *grad_w1, float *dgamma0, float *dbeta0, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 /* The second half of hf_bn_relu_bwd alone: dx from dy, x and ALREADY KNOWN dgamma / dbeta (no reduction pass). */
 int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
                       const float *save_mean, const float *save_invstd, const float *dgamma, const float *dbeta, int relu,

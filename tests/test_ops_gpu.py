@@ -1699,7 +1699,9 @@ def test_dense_chain_elu_node_equals_layer_by_layer(cin, c):
     go = torch.randn(8, rows // 8, c, device="cuda") / rows
     params = [d0.linear.weight, d0.post.bn.weight, d0.post.bn.bias, d1.linear.weight, d1.post.bn.weight, d1.post.bn.bias]
     rm = [d.post.bn.running_mean.clone() for d in (d0, d1)]
-    out_a = pc.dense_chain(d0, d1, x)
+    out_a = pc.dense_chain(d0, d1, x)          # cin = 3: the recompute form (_LiftChain), else the stored form (_DenseChainElu)
+    node = out_a.grad_fn.next_functions[0][0].__class__.__name__          # below the reshape
+    assert node.startswith("_LiftChain" if cin == 3 else "_DenseChainElu"), node
     g_a = torch.autograd.grad(out_a, params, go)
     rm_a = [d.post.bn.running_mean.clone() for d in (d0, d1)]
     for d, r in zip((d0, d1), rm):
