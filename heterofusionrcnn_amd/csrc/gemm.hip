@@ -569,9 +569,14 @@ __device__ __forceinline__ void lift_tab_load(LiftTab &T, int c, const float *__
     }
 }
 __device__ __forceinline__ float lift_z(float wx, float wy, float wz, float x0, float x1, float x2) { return (x0 * wx + x1 * wy) + x2 * wz; }
+// the first layer's ELU is evaluated five times per element instead of once, and expm1f (~30 instructions) made the lift
+// kernels VALU-bound (the forward wrote its 268 MB in 119 us); exp(x) - 1 on the hardware exponential is TensorFlow's own
+// formula for tf.nn.elu (Eigen: x < 0 ? exp(x) - 1 : x) and two instructions
+__device__ __forceinline__ float lift_elu(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+__device__ __forceinline__ float lift_elu_slope(float x) { return x > 0.0f ? 1.0f : __expf(x); }
 __device__ __forceinline__ float lift_y(const LiftTab &T, int k, float x0, float x1, float x2)
 {
-    return T.a[k] * (elu_fwd(lift_z(T.wx[k], T.wy[k], T.wz[k], x0, x1, x2)) - T.mu[k]) + T.be[k];
+    return T.a[k] * (lift_elu(lift_z(T.wx[k], T.wy[k], T.wz[k], x0, x1, x2)) - T.mu[k]) + T.be[k];
 }
 
 // batch statistics of elu(W0 x): a lane owns a channel, the waves of a block walk a chunk of rows (x is wave-uniform)
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(256) void lift_stats_kernel(long long rows, int c, 
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s = 0.f, q = 0.f;
     for (long long r = r0 + wave; r < r1; r += 4) {
-        const float e = elu_fwd(lift_z(wx, wy, wz, x3[3 * r], x3[3 * r + 1], x3[3 * r + 2]));
+        const float e = lift_elu(lift_z(wx, wy, wz, x3[3 * r], x3[3 * r + 1], x3[3 * r + 2]));
         s += e;
         q += e * e;
     }
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                 const float v = acc[nt][g];
                 if (col < cout && row < rows) {
                     Z[row * cout + col] = v;
-                    const float sv = elu_fwd(v);
+                    const float sv = lift_elu(v);   // 32 expm1f per lane and tile cost as much as the tile's MFMAs; |difference| <= 6e-8
                     s1[nt] += sv;
                     s2[nt] += sv * sv;
                 }
@@ -901,12 +906,12 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                 if (nt * 32 + (lane & 31) >= c0) continue;
                 const float v = acc[nt][g];
                 const float z0 = lift_z(wx[nt], wy[nt], wz[nt], x0, x1, x2);
-                const float xhat = (elu_fwd(z0) - pmu[nt]) * pis[nt];
+                const float xhat = (lift_elu(z0) - pmu[nt]) * pis[nt];
                 if (PASS == 0) {
                     acc_s[nt][0] += v;
                     acc_s[nt][1] += v * xhat;
                 } else {
-                    const float dz0 = pa[nt] * (v - c1[nt] - xhat * c2[nt]) * elu_slope(z0);
+                    const float dz0 = pa[nt] * (v - c1[nt] - xhat * c2[nt]) * lift_elu_slope(z0);
                     acc_s[nt][0] += dz0 * x0;
                     acc_s[nt][1] += dz0 * x1;
                     acc_s[nt][NV - 1] += dz0 * x2;
