@@ -74,9 +74,9 @@ def test_golden_grouping(hf):
 def _fps_both_kernels(hf, m, xyz_dev):
     """run the plain and the bucketed FPS kernel (hf_farthest_point_sample_variant) and insist they agree"""
     outs = []
-    for mode in ("plain", "bucket"):
-        outs.append(hf.farthest_point_sample(m, xyz_dev, kernel=mode))
-    assert torch.equal(outs[0], outs[1]), "plain and bucketed FPS disagree"
+    for mode, nt in (("plain", 0), ("bucket", 512), ("bucket", 1024)):     # 8 waves x 32 buckets / 16 waves x 16 buckets
+        outs.append(hf.farthest_point_sample(m, xyz_dev, kernel=mode, threads=nt))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "plain and bucketed FPS disagree"
     auto = hf.farthest_point_sample(m, xyz_dev)
     assert torch.equal(auto, outs[0])
     return auto
@@ -1356,7 +1356,7 @@ def test_fuzz_all_ops_against_oracle(hf, oracle_mod):
         # FPS on every kernel
         mm = int(min(n + 3, rng.choice([1, 2, 17, 128, 700])))
         want = oracle_mod.farthest_point_sample(mm, x1)
-        variants = [("plain", 1024), ("plain", 512), ("bucket", 0)] + ([("plain", 256)] if n <= 4096 else [])
+        variants = [("plain", 1024), ("plain", 512), ("bucket", 0), ("bucket", 512), ("bucket", 1024)] + ([("plain", 256)] if n <= 4096 else [])
         for mode, nt in variants:
             got = hf.farthest_point_sample(mm, dev(x1), kernel=mode, threads=nt)
             assert np.array_equal(host(got), want), (trial, mode, nt, b, n, mm)
