@@ -102,6 +102,8 @@ _SIGNATURES = {
     "hf_xconv_apply_grad": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_depthwise_k": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp],
     "hf_depthwise_k_grad": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hf_depthwise_k_grad_workspace": [ctypes.c_longlong, _i, _i, _i],
+    "hf_depthwise_k_grad_ws": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_xconv_depthwise": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "hf_xconv_depthwise_grad": [ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_xconv_depthwise_gather": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -125,6 +127,7 @@ _RESTYPES = {
     "hf_linear_bn_bwd_workspace": _sz,
     "hf_xconv_depthwise_gather_grad_workspace": _sz,
     "hf_lift_elu_bn_fwd_workspace": _sz,
+    "hf_depthwise_k_grad_workspace": _sz,
     "hf_lift_elu_bn_bwd_workspace": _sz,
     "hf_version": ctypes.c_char_p,
     "hf_strerror": ctypes.c_char_p,

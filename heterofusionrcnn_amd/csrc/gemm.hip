@@ -990,6 +990,11 @@ static int resident_grid(int nt, long long ntiles)
     return static_cast<int>(g);
 }
 
+void launch_partial_reduce(int total, int chunks, const float *partial, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(total, 64)), dim3(64 * kWredGroups), 0, st, total, chunks, partial, out);
+}
+
 static bool vec4_ok(const void *p, int ncols) { return ncols % 4 == 0 && reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 }  // namespace hf

@@ -29,6 +29,8 @@ void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *part
                               hipStream_t st);
 // mlp.hip: fp64 reduction of BN-backward partials (sum dh, sum dh*xhat) -> dbeta, dgamma
 void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma, float *dbeta, hipStream_t st);
+// out[e] = sum over chunks of partial[chunk * total + e], chunks added in a fixed order (gemm.hip)
+void launch_partial_reduce(int total, int chunks, const float *partial, float *out, hipStream_t st);
 
 // grouping.hip: k nearest data points of every query on a 2-D grid (binning + ring search), any k <= 75; fewer than k
 // data points leave (+inf, index 0) in the unfilled slots.  workspace: knn_grid_workspace(b, n) bytes, 16-byte aligned.

@@ -145,10 +145,14 @@ __global__ __launch_bounds__(kXcThreads) void depthwise_dx_kernel(long long rows
 // dW[w][ch][m] = sum_r x[r][w][ch] * dy[r][ch*M + m]: thread (row chunk, channel) sums its rows in registers, then one
 // atomic per coefficient and chunk (grad_w zero-filled by the entry point).  The order of the chunks is not fixed: the
 // sum is reproducible to fp32 rounding, not bit for bit.
+//
+// `partial` != NULL (hf_depthwise_k_grad_ws): every chunk writes its K*c*M sums to partial[chunk][...] instead and a second
+// kernel adds the chunks in a fixed order -- 512 chunks x 512 atomics on the same 16 cache lines were 50 us of a 60 us call
+// for the X-transform's 8-channel layers, whatever the number of rows; deterministic as a bonus.
 template <int K, int M>
 __global__ __launch_bounds__(kXcThreads) void depthwise_dw_kernel(long long rows, int c, int rows_per_chunk,
                                                                  const float *__restrict__ x, const float *__restrict__ grad_y,
-                                                                 float *__restrict__ grad_w)
+                                                                 float *__restrict__ grad_w, float *__restrict__ partial)
 {
     // narrow layers (the X-transform has 8 channels): the threads a block has beyond the channels split the chunk's rows,
     // their partial sums meet in LDS, and the block issues ONE atomic per coefficient (8 x 8 x 8 coefficients hit by a
@@ -182,12 +186,46 @@ __global__ __launch_bounds__(kXcThreads) void depthwise_dw_kernel(long long rows
             }
         }
     }
+    float *mine = partial ? partial + static_cast<size_t>(blockIdx.y) * K * c * M : nullptr;
     if (nrs == 1) {
         if (live) {
 #pragma unroll
             for (int w = 0; w < K; ++w)
 #pragma unroll
-                for (int m = 0; m < M; ++m) atomicAdd(&grad_w[(static_cast<size_t>(w) * c + ch) * M + m], acc[w][m]);
+                for (int m = 0; m < M; ++m) {
+                    const size_t e = (static_cast<size_t>(w) * c + ch) * M + m;
+                    if (mine) mine[e] = acc[w][m];
+                    else atomicAdd(&grad_w[e], acc[w][m]);
+                }
+        }
+        return;
+    }
+    // the row slots of a channel meet: inside a wave by xor-shuffles (power-of-two channel counts up to 32: the lanes of a
+    // wave are 64 / cw row slots x cw channels), then one LDS slot per wave.  LDS atomics here -- 64 per thread, eight lanes of
+    // a wave on every address -- were 13 us of serialised LDS work per block, the whole cost of the 8-channel layers.
+    const bool shuffle = (cw & (cw - 1)) == 0 && cw <= 32;
+    if (shuffle) {
+        const int lane = t & 63, wave = t >> 6;
+        __syncthreads();   // the zero fill above is not needed on this path, but every thread must be past it
+#pragma unroll
+        for (int w = 0; w < K; ++w)
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                float v = live ? acc[w][m] : 0.f;
+                for (int off = cw; off < 64; off <<= 1) v += __shfl_xor(v, off);
+                if (lane < cw) red[(wave * K * M + w * M + m) * cw + lane] = v;
+            }
+        __syncthreads();
+        for (int i = t; i < K * M * cw; i += kXcThreads) {
+            float v = red[i];
+#pragma unroll
+            for (int wv = 1; wv < kXcThreads / 64; ++wv) v += red[wv * K * M * cw + i];
+            const int wm = i / cw, c2 = blockIdx.x * cw + i % cw;
+            if (c2 < c) {
+                const size_t e = (static_cast<size_t>(wm / M) * c + c2) * M + wm % M;
+                if (mine) mine[e] = v;
+                else atomicAdd(&grad_w[e], v);
+            }
         }
         return;
     }
@@ -200,7 +238,11 @@ __global__ __launch_bounds__(kXcThreads) void depthwise_dw_kernel(long long rows
     __syncthreads();
     for (int i = t; i < K * M * cw; i += kXcThreads) {
         const int wm = i / cw, c2 = blockIdx.x * cw + i % cw;
-        if (c2 < c) atomicAdd(&grad_w[(static_cast<size_t>(wm / M) * c + c2) * M + wm % M], red[i]);
+        if (c2 < c) {
+            const size_t e = (static_cast<size_t>(wm / M) * c + c2) * M + wm % M;
+            if (mine) mine[e] = red[i];
+            else atomicAdd(&grad_w[e], red[i]);
+        }
     }
 }
 
@@ -582,12 +624,32 @@ HF_API int hf_depthwise_k(long long rows, int k, int c, int m, const float *x, c
     return launch_status();
 }
 
-HF_API int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float *x, const float *w, const float *grad_y,
-                               float *grad_x, float *grad_w, hf_stream_t stream)
+static void dw_chunks(long long rows, int c, int &cblocks, int &rows_per_chunk, unsigned &nchunks)
 {
-    if (rows < 0 || c <= 0 || !x || !w || !grad_y || (!grad_x && !grad_w)) return HF_EINVAL;
-    hipStream_t st = as_stream(stream);
-    if (grad_w) {
+    // enough chunks to fill the chip, few enough that the per-chunk tail stays a footnote; at least 64 rows per chunk
+    cblocks = c < kXcThreads ? 1 : div_up(c, kXcThreads);
+    long long chunks = (2 * kNumCU + cblocks - 1) / cblocks;
+    if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > rows) chunks = rows;
+    if (chunks > 65535) chunks = 65535;
+    rows_per_chunk = static_cast<int>((rows + chunks - 1) / chunks);
+    nchunks = static_cast<unsigned>((rows + rows_per_chunk - 1) / rows_per_chunk);
+}
+
+HF_API size_t hf_depthwise_k_grad_workspace(long long rows, int k, int c, int m)
+{
+    if (rows <= 0 || k <= 0 || c <= 0 || m <= 0) return 0;
+    int cblocks, rpc;
+    unsigned nchunks;
+    dw_chunks(rows, c, cblocks, rpc, nchunks);
+    return sizeof(float) * static_cast<size_t>(nchunks) * k * c * m;
+}
+
+static int depthwise_k_grad_impl(long long rows, int k, int c, int m, const float *x, const float *w, const float *grad_y,
+                                 float *grad_x, float *grad_w, float *partial, hipStream_t st)
+{
+    if (grad_w && (!partial || rows == 0)) {
         const int rc = hip_status(hipMemsetAsync(grad_w, 0, sizeof(float) * static_cast<size_t>(k) * c * m, st));
         if (rc != HF_OK) return rc;
     }
@@ -601,25 +663,36 @@ HF_API int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float 
         if (rc != HF_OK) return rc;
     }
     if (grad_w) {
-        // enough chunks to fill the chip, few enough that the atomics stay a footnote
-        const int cblocks = c < kXcThreads ? 1 : div_up(c, kXcThreads);
-        const size_t lds = c <= kXcThreads / 2 ? sizeof(float) * static_cast<size_t>(k) * m * c : 0;   // block-level reduction when a block holds >= 2 row slots
+        int cblocks, rows_per_chunk;
+        unsigned nchunks;
+        dw_chunks(rows, c, cblocks, rows_per_chunk, nchunks);
+        // block-level reduction when a block holds >= 2 row slots (one slot per wave on the shuffle path)
+        const size_t lds = c <= kXcThreads / 2 ? sizeof(float) * static_cast<size_t>(k) * m * c * (((c & (c - 1)) == 0 && c <= 32) ? kXcThreads / 64 : 1) : 0;
         if (lds > 48 * 1024) return HF_EINVAL;
-        long long chunks = (2 * kNumCU + cblocks - 1) / cblocks;
-        // every chunk ends in one atomic per coefficient on the SAME k*c*m addresses: with few rows (one frame per GPU) 512
-        // chunks were 40 us of serialised atomics for 5 us of work; at least 64 rows per chunk
-        if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
-        if (chunks < 1) chunks = 1;
-        if (chunks > rows) chunks = rows;
-        if (chunks > 65535) chunks = 65535;
-        const int rows_per_chunk = static_cast<int>((rows + chunks - 1) / chunks);
-        const dim3 grid(cblocks, static_cast<unsigned>((rows + rows_per_chunk - 1) / rows_per_chunk));
-#define HF_DW_DW(KK, MM) hipLaunchKernelGGL((depthwise_dw_kernel<KK, MM>), grid, dim3(kXcThreads), lds, st, rows, c, rows_per_chunk, x, grad_y, grad_w);
+        const dim3 grid(cblocks, nchunks);
+#define HF_DW_DW(KK, MM) hipLaunchKernelGGL((depthwise_dw_kernel<KK, MM>), grid, dim3(kXcThreads), lds, st, rows, c, rows_per_chunk, x, grad_y, grad_w, partial);
         HF_DW_DISPATCH(HF_DW_DW)
 #undef HF_DW_DW
+        if (partial) launch_partial_reduce(k * c * m, static_cast<int>(nchunks), partial, grad_w, st);
         return launch_status();
     }
     return HF_OK;
+}
+
+HF_API int hf_depthwise_k_grad(long long rows, int k, int c, int m, const float *x, const float *w, const float *grad_y,
+                               float *grad_x, float *grad_w, hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !w || !grad_y || (!grad_x && !grad_w)) return HF_EINVAL;
+    return depthwise_k_grad_impl(rows, k, c, m, x, w, grad_y, grad_x, grad_w, nullptr, as_stream(stream));
+}
+
+HF_API int hf_depthwise_k_grad_ws(long long rows, int k, int c, int m, const float *x, const float *w, const float *grad_y,
+                                  float *grad_x, float *grad_w, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows < 0 || c <= 0 || !x || !w || !grad_y || (!grad_x && !grad_w)) return HF_EINVAL;
+    if (grad_w && rows > 0 && (!workspace || workspace_bytes < hf_depthwise_k_grad_workspace(rows, k, c, m))) return HF_EWORKSPACE;
+    return depthwise_k_grad_impl(rows, k, c, m, x, w, grad_y, grad_x, grad_w, grad_w ? static_cast<float *>(workspace) : nullptr,
+                                 as_stream(stream));
 }
 
 // (k, m) supported by the fused X-apply + depthwise kernels: k = 8, m = 1..4 (the separable convolutions of pointcnn.py:259-265)

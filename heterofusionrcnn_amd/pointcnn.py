@@ -314,7 +314,10 @@ class _DepthwiseK(torch.autograd.Function):
         gy = gy.reshape(-1, c * m).contiguous()
         gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        check(_lib.lib().hf_depthwise_k_grad(x2.shape[0], k, c, m, ptr(x2), ptr(w), ptr(gy), ptr(gx), ptr(gw), stream_ptr()),
+        L = _lib.lib()
+        nbytes = L.hf_depthwise_k_grad_workspace(x2.shape[0], k, c, m) if gw is not None else 0
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x2.device) if nbytes else None
+        check(L.hf_depthwise_k_grad_ws(x2.shape[0], k, c, m, ptr(x2), ptr(w), ptr(gy), ptr(gx), ptr(gw), ptr(ws), nbytes, stream_ptr()),
               "depthwise_k_grad")
         return (gx.reshape(*ctx.lead, k, c) if gx is not None else None), gw
 
