@@ -109,7 +109,7 @@ _SIGNATURES = {
     "hf_xconv_depthwise_gather": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "hf_xconv_depthwise_gather_grad": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _sz, _vp],
-    "hf_xconv_depthwise_gather_grad_workspace": [_i, _i, _i, _i],
+    "hf_xconv_depthwise_gather_grad_workspace": [_i, _i, _i, _i, _i, _i],
     "hf_version": [],
     "hf_strerror": [_i],
     "hf_last_hip_error": [],

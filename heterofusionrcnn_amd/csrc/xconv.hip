@@ -331,13 +331,14 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long r
                                                                     const float *__restrict__ fts, const int *__restrict__ idx, int n_src,
                                                                     int rows_per_cloud, const float *__restrict__ wd,
                                                                     const float *__restrict__ grad_out, float *__restrict__ grad_f,
-                                                                    float *__restrict__ grad_gathered, float *__restrict__ grad_wd)
+                                                                    float *__restrict__ grad_gathered, float *__restrict__ grad_wd,
+                                                                    float *__restrict__ wd_partial)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int ch = blockIdx.y * 64 + lane;
     const bool live = ch < c;
     const XcSource src = xc_source(live ? ch : blockIdx.y * 64, c, c0, f, fts, GATHER ? idx : nullptr);
-    if (GATHER && src.gathered && !grad_wd && !grad_gathered) return;   // nothing of this chunk is asked for
+    if (GATHER && src.gathered && !grad_wd && !grad_gathered) return;   // nothing of this chunk is asked for (no partial to write either)
     float w[K][M], gw[K][M];
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -392,9 +393,16 @@ __global__ __launch_bounds__(kXcThreads) void xconv_dw_bwd_fw_kernel(long long r
                 for (int m = 0; m < M; ++m) atomicAdd(&red[k * M + m][lane], gw[k][m]);
         }
         __syncthreads();
+        // wd_partial: the row chunks' sums are written out (wd_partial[row chunk][K*c*M]) and added in a fixed order by a second
+        // kernel; else one global atomic per coefficient and block on grad_wd (zero-filled by the entry point)
+        float *mine = wd_partial ? wd_partial + static_cast<size_t>(blockIdx.x) * K * c * M : nullptr;
         for (int i = threadIdx.x; i < K * M * 64; i += kXcThreads) {
             const int km = i >> 6, c2 = blockIdx.y * 64 + (i & 63);
-            if (c2 < c) atomicAdd(&grad_wd[(static_cast<size_t>(km / M) * c + c2) * M + km % M], red[km][i & 63]);
+            if (c2 < c) {
+                const size_t e = (static_cast<size_t>(km / M) * c + c2) * M + km % M;
+                if (mine) mine[e] = red[km][i & 63];
+                else atomicAdd(&grad_wd[e], red[km][i & 63]);
+            }
         }
     }
 }
@@ -724,27 +732,35 @@ static int xdw_forward(long long rows, int k, int c, int c0, int m, const float 
     return launch_status();
 }
 
+// grid of xconv_dw_bwd_fw_kernel: every block ends in one sum per weight coefficient (an atomic on the same k*c*m addresses, or a
+// row of the partial buffer): 4 blocks per CU, and at least 32 rows per block (one frame per GPU: the deep layers have a few
+// hundred rows)
+static void xdw_bwd_grid(long long rows, int c, dim3 &grid, int &rpb)
+{
+    xdw_grid(rows, c, grid, rpb, 4);
+    if (rpb < 32 && rows > 32) { rpb = 32; grid.x = static_cast<unsigned>((rows + rpb - 1) / rpb); }
+}
+
 static int xdw_backward(long long rows, int k, int c, int c0, int m, const float *x, const float *f, const float *fts, const int *idx,
                         int n_src, int rows_per_cloud, const float *wd, const float *grad_out, float *grad_x, float *grad_f, float *grad_gathered,
-                        float *grad_wd, hipStream_t st)
+                        float *grad_wd, hipStream_t st, float *wd_partial = nullptr)
 {
-    if (grad_wd) {
+    if (grad_wd && (!wd_partial || rows == 0)) {
         const int rc = hip_status(hipMemsetAsync(grad_wd, 0, sizeof(float) * static_cast<size_t>(k) * c * m, st));
         if (rc != HF_OK) return rc;
     }
     if (rows == 0) return HF_OK;
+    if (!grad_wd) wd_partial = nullptr;
     if (grad_f || grad_wd || grad_gathered) {
         dim3 grid;
         int rpb;
-        // every block ends in one atomic per weight coefficient on the same k*c*m addresses: 4 blocks per CU, and at least 32
-        // rows per block (one frame per GPU: the deep layers have a few hundred rows)
-        xdw_grid(rows, c, grid, rpb, 4);
-        if (rpb < 32 && rows > 32) { rpb = 32; grid.x = static_cast<unsigned>((rows + rpb - 1) / rpb); }
+        xdw_bwd_grid(rows, c, grid, rpb);
 #define HF_XDW_BFW(KK, MM)                                                                                             \
-        if (idx) hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, true>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_gathered, grad_wd); \
-        else hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, false>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_gathered, grad_wd);
+        if (idx) hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, true>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_gathered, grad_wd, wd_partial); \
+        else hipLaunchKernelGGL((xconv_dw_bwd_fw_kernel<KK, MM, false>), grid, dim3(kXcThreads), 0, st, rows, c, c0, rpb, x, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_f, grad_gathered, grad_wd, wd_partial);
         HF_XDW_DISPATCH(HF_XDW_BFW)
 #undef HF_XDW_BFW
+        if (wd_partial) launch_partial_reduce(k * c * m, static_cast<int>(grid.x), wd_partial, grad_wd, st);
         const int rc = launch_status();
         if (rc != HF_OK) return rc;
     }
@@ -794,10 +810,19 @@ HF_API int hf_xconv_depthwise_gather(int b, int n_src, int rows_per_cloud, int k
     return xdw_forward(rows, k, c0 + c1, c0, m, x, f_delta, fts, idx, n_src, rows_per_cloud, wd, out, as_stream(stream));
 }
 
-HF_API size_t hf_xconv_depthwise_gather_grad_workspace(int b, int rows_per_cloud, int k, int c1)
+// [gradient of the gathered block: rows x k x c1][partial depthwise-weight gradients: row chunks x k x (c0+c1) x m]
+static size_t xdw_gathered_bytes(int b, int rows_per_cloud, int k, int c1)
 {
-    if (b <= 0 || rows_per_cloud <= 0 || k <= 0 || c1 <= 0) return 0;
-    return sizeof(float) * static_cast<size_t>(b) * rows_per_cloud * k * c1;
+    return (sizeof(float) * static_cast<size_t>(b) * rows_per_cloud * k * c1 + 255) & ~static_cast<size_t>(255);
+}
+
+HF_API size_t hf_xconv_depthwise_gather_grad_workspace(int b, int rows_per_cloud, int k, int c0, int c1, int m)
+{
+    if (b <= 0 || rows_per_cloud <= 0 || k <= 0 || c0 <= 0 || c1 <= 0 || m <= 0) return 0;
+    dim3 grid;
+    int rpb;
+    xdw_bwd_grid(static_cast<long long>(b) * rows_per_cloud, c0 + c1, grid, rpb);
+    return xdw_gathered_bytes(b, rows_per_cloud, k, c1) + sizeof(float) * static_cast<size_t>(grid.x) * k * (c0 + c1) * m;
 }
 
 HF_API int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
@@ -811,7 +836,7 @@ HF_API int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, 
         (!grad_x && !grad_f_delta && !grad_fts && !grad_wd))
         return HF_EINVAL;
     if (grad_fts && (!offsets || !entries)) return HF_EINVAL;
-    if (workspace && workspace_bytes < hf_xconv_depthwise_gather_grad_workspace(b, rows_per_cloud, k, c1)) return HF_EWORKSPACE;
+    if (workspace && workspace_bytes < hf_xconv_depthwise_gather_grad_workspace(b, rows_per_cloud, k, c0, c1, m)) return HF_EWORKSPACE;
     hipStream_t st = as_stream(stream);
     const long long rows = static_cast<long long>(b) * rows_per_cloud;
     const int c = c0 + c1;
@@ -819,9 +844,10 @@ HF_API int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, 
     // hf_group_point_grad_gather (240 us + 230 us of extra writes at the last decoder layer); without one it is rebuilt per
     // table row from grad_out (no extra memory, 890 us there)
     float *gathered = (grad_fts && workspace) ? static_cast<float *>(workspace) : nullptr;
+    float *wd_partial = workspace ? reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + xdw_gathered_bytes(b, rows_per_cloud, k, c1)) : nullptr;
     if (grad_x || grad_f_delta || grad_wd || gathered) {
         const int rc = xdw_backward(rows, k, c, c0, m, x, f_delta, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_x, grad_f_delta, gathered,
-                                    grad_wd, st);
+                                    grad_wd, st, wd_partial);
         if (rc != HF_OK) return rc;
     }
     if (grad_fts) {

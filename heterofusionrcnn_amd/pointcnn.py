@@ -425,8 +425,9 @@ class _XConvDepthwiseGather(torch.autograd.Function):
         require(gt is None or inv, "xconv_depthwise_gather: the gradient of the feature table needs the inverse neighbour table")
         off, ent = inv if inv else (None, None)
         L = _lib.lib()
-        # the gathered block's gradient is staged once in a workspace (freed right after) and summed per table row
-        nbytes = L.hf_xconv_depthwise_gather_grad_workspace(b, p, k, c1) if (gt is not None and ctx.use_workspace) else 0
+        # the gathered block's gradient is staged once in a workspace (freed right after) and summed per table row; the row
+        # chunks' partial weight gradients go through it as well (fixed-order sum instead of atomics)
+        nbytes = L.hf_xconv_depthwise_gather_grad_workspace(b, p, k, c0, c1, m) if ctx.use_workspace else 0
         ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=go.device) if nbytes else None
         check(L.hf_xconv_depthwise_gather_grad(b, n, p, k, c0, c1, m, ptr(x2), ptr(f2), ptr(t2), ptr(idx), ptr(w), ptr(go),
                                                ptr(off), ptr(ent), ptr(gx), ptr(gf), ptr(gt), ptr(gw), ptr(ws), nbytes, stream_ptr()),

@@ -493,8 +493,9 @@ int hf_depthwise_k_grad_ws(long long rows, int k, int c, int m, const float *x, 
  * entries (b, rows_per_cloud*k) from hf_index_inverse): every table row is written once, summed in ascending (row, slot) order
  * like hf_group_point_grad_gather; no atomics, no zero fill.  Any gradient may be NULL.  workspace
  * (hf_xconv_depthwise_gather_grad_workspace bytes, may be NULL): with it the gathered block's gradient is written once and summed
- * per table row (faster); without it it is rebuilt per table row from grad_out (no extra memory).  Same values either way. */
-size_t hf_xconv_depthwise_gather_grad_workspace(int b, int rows_per_cloud, int k, int c1);
+ * per table row (faster; without it it is rebuilt per table row from grad_out: no extra memory, same values), and the row
+ * chunks' partial depthwise-weight gradients are added in a fixed order instead of meeting in atomics (deterministic grad_wd). */
+size_t hf_xconv_depthwise_gather_grad_workspace(int b, int rows_per_cloud, int k, int c0, int c1, int m);
 int hf_xconv_depthwise_gather(int b, int n_src, int rows_per_cloud, int k, int c0, int c1, int m, const float *x,
                               const float *f_delta, const float *fts, const int *idx, const float *wd, float *out,
                               hf_stream_t stream);

@@ -141,8 +141,11 @@ def test_xconv_gather_and_elu_chain_argument_checks():
     assert L.hf_xconv_depthwise_gather(2, 100, 50, 8, 64, 0, 1, one, one, one, one, one, one, None) == _lib.HF_EINVAL      # nothing to gather
     assert L.hf_xconv_depthwise_gather(*ok, one, one, None, one, one, one, None) == _lib.HF_EINVAL                          # no feature table
     assert L.hf_xconv_depthwise_gather(0, 100, 50, 8, 64, 32, 1, one, one, one, one, one, one, None) == _lib.HF_OK          # empty batch
-    assert L.hf_xconv_depthwise_gather_grad_workspace(2, 50, 8, 32) == 4 * 2 * 50 * 8 * 32
-    assert L.hf_xconv_depthwise_gather_grad_workspace(0, 50, 8, 32) == 0
+    # [gradient of the gathered block, 256-byte multiple][one row of k * (c0 + c1) * m partial weight sums per row chunk]
+    ws = L.hf_xconv_depthwise_gather_grad_workspace(2, 50, 8, 64, 32, 1)
+    gathered = (4 * 2 * 50 * 8 * 32 + 255) // 256 * 256
+    assert ws > gathered and (ws - gathered) % (4 * 8 * 96) == 0
+    assert L.hf_xconv_depthwise_gather_grad_workspace(0, 50, 8, 64, 32, 1) == 0
     grads_none = (None, None, None, None)
     assert L.hf_xconv_depthwise_gather_grad(*ok, one, one, one, one, one, one, one, one, *grads_none, None, 0, None) == _lib.HF_EINVAL
     # a gradient of the feature table needs the inverse neighbour table; a workspace must be large enough
