@@ -58,7 +58,8 @@ int hf_last_hip_error(void); /* hipError_t of the last HF_EHIP on this thread */
 int hf_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, hf_stream_t stream);
 /* The same op with the kernel forced (the tests run every kernel against the oracle): HF_FPS_PLAIN = points and running
  * distances in registers, `threads` = 256 / 512 / 1024 per cloud (0: by size); HF_FPS_BUCKET = the spatially bucketed kernel
- * with exact pruning; HF_FPS_AUTO = what hf_farthest_point_sample picks.  Identical output whatever the choice. */
+ * with exact pruning, `threads` = 1024 (16 waves x 16 buckets) or anything else = 512 (8 waves x 32 buckets, the default);
+ * HF_FPS_AUTO = what hf_farthest_point_sample picks (bucketed from 8192 points).  Identical output whatever the choice. */
 #define HF_FPS_AUTO 0
 #define HF_FPS_PLAIN 1
 #define HF_FPS_BUCKET 2
