@@ -703,10 +703,14 @@ HF_API int hf_depthwise_k_grad_ws(long long rows, int k, int c, int m, const flo
                                  as_stream(stream));
 }
 
-// (k, m) supported by the fused X-apply + depthwise kernels: k = 8, m = 1..4 (the separable convolutions of pointcnn.py:259-265)
+// (k, m) supported by the fused X-apply + depthwise kernels: k = 8 with m = 1..4 (the separable convolutions of pointcnn.py:259-265
+// under rpn_multiclass.config), and the RCNN's (4, 1), (4, 4), (12, 1), (12, 2)
 #define HF_XDW_DISPATCH(CALL)                                                                                          \
     if (k == 8 && m == 1) { CALL(8, 1) } else if (k == 8 && m == 2) { CALL(8, 2) } else if (k == 8 && m == 3) { CALL(8, 3) }      \
-    else if (k == 8 && m == 4) { CALL(8, 4) } else return HF_EINVAL;
+    else if (k == 8 && m == 4) { CALL(8, 4) }                                                                          \
+    else if (k == 4 && m == 1) { CALL(4, 1) } else if (k == 4 && m == 4) { CALL(4, 4) }   /* rcnn_multiclass.config:157-186: K = 4, 8, 12, 12 */ \
+    else if (k == 12 && m == 1) { CALL(12, 1) } else if (k == 12 && m == 2) { CALL(12, 2) }                             \
+    else return HF_EINVAL;
 
 static void xdw_grid(long long rows, int c, dim3 &grid, int &rows_per_block, int blocks_per_cu = 8)
 {
@@ -765,20 +769,12 @@ static int xdw_backward(long long rows, int k, int c, int c0, int m, const float
         if (rc != HF_OK) return rc;
     }
     if (grad_x) {
-        const size_t lds = sizeof(float) * (kXcThreads / 64) * 16 * (8 * 8 + 1);
-        static bool raised = false;
-#define HF_XDW_RAISE(KK, MM, G) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dw_bwd_x_kernel<KK, MM, G>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        const size_t lds = sizeof(float) * (kXcThreads / 64) * 16 * (static_cast<size_t>(k) * k + 1);   // <= 37 KB at K = 12
 #define HF_XDW_BX(KK, MM)                                                                                              \
-        if (!raised) {                                                                                                 \
-            HF_XDW_RAISE(KK, 1, false) HF_XDW_RAISE(KK, 2, false) HF_XDW_RAISE(KK, 3, false) HF_XDW_RAISE(KK, 4, false)    \
-            HF_XDW_RAISE(KK, 1, true) HF_XDW_RAISE(KK, 2, true) HF_XDW_RAISE(KK, 3, true) HF_XDW_RAISE(KK, 4, true)        \
-            raised = true;                                                                                             \
-        }                                                                                                              \
         if (idx) hipLaunchKernelGGL((xconv_dw_bwd_x_kernel<KK, MM, true>), dim3(grid_for(rows, kXcThreads / 64)), dim3(kXcThreads), lds, st, rows, c, c0, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_x); \
         else hipLaunchKernelGGL((xconv_dw_bwd_x_kernel<KK, MM, false>), dim3(grid_for(rows, kXcThreads / 64)), dim3(kXcThreads), lds, st, rows, c, c0, f, fts, idx, n_src, rows_per_cloud, wd, grad_out, grad_x);
         HF_XDW_DISPATCH(HF_XDW_BX)
 #undef HF_XDW_BX
-#undef HF_XDW_RAISE
         return launch_status();
     }
     return HF_OK;

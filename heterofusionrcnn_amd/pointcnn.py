@@ -435,7 +435,7 @@ class _XConvDepthwiseGather(torch.autograd.Function):
         return (gx.reshape(sx) if gx is not None else None), (gf.reshape(sf) if gf is not None else None), gt, None, None, None, gw, None
 
 
-_XDW_KM = {(8, 1), (8, 2), (8, 3), (8, 4)}
+_XDW_KM = {(8, 1), (8, 2), (8, 3), (8, 4), (4, 1), (4, 4), (12, 1), (12, 2)}
 
 
 def xconv_depthwise_gather(x, f_delta, fts, idx, wd, inverse=None, use_workspace=True):

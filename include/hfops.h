@@ -469,7 +469,8 @@ int hf_xconv_apply_grad(long long rows, int k, int c, const float *x, const floa
                         float *grad_f, hf_stream_t stream);
 int hf_depthwise_k(long long rows, int k, int c, int m, const float *x, const float *w, float *y, hf_stream_t stream);
 /* hf_xconv_apply followed by hf_depthwise_k in ONE pass (pointcnn.py:133-140): out (rows, c*m) from x (rows,k,k),
- * f (rows,k,c), wd (k,c,m) without the (rows,k,c) product in memory; bit-identical to the two calls.  k = 8, m in 1..4.
+ * f (rows,k,c), wd (k,c,m) without the (rows,k,c) product in memory; bit-identical to the two calls.  (k, m): k = 8 with
+ * m in 1..4, and (4,1), (4,4), (12,1), (12,2) (the RCNN's layers, rcnn_multiclass.config:157-186).
  * hf_xconv_depthwise_grad: grad_x (rows,k,k), grad_f (rows,k,c), grad_wd (k,c,m; zero-filled here, atomics), any may be NULL. */
 int hf_xconv_depthwise(long long rows, int k, int c, int m, const float *x, const float *f, const float *wd, float *out,
                        hf_stream_t stream);

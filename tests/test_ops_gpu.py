@@ -1726,3 +1726,32 @@ def test_dense_chain_elu_node_equals_layer_by_layer(cin, c):
         assert float((b - r.float()).abs().max()) <= 2e-3 * scale + 1e-9, name
     for a, b in zip(rm_a, rm_b):
         assert float((a - b).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,m,c0,c1", [(4, 4, 128, 33), (12, 2, 128, 64), (12, 1, 256, 40), (4, 1, 64, 64)])
+def test_xconv_depthwise_kernels_at_the_rcnn_neighbourhood_sizes(k, m, c0, c1):
+    """the fused X-apply + depthwise kernels (dense and in-place-gather form) at K = 4 and K = 12 (rcnn_multiclass.config:157-186)
+    against torch.matmul followed by the einsum form of the depthwise step, forward and all four gradients"""
+    from heterofusionrcnn_amd import pointcnn as pc
+    from heterofusionrcnn_amd.grouping import index_inverse
+    torch.manual_seed(k * 10 + m)
+    b, n, p = 2, 200, 90
+    dev = "cuda"
+    x = torch.randn(b, p, k, k, device=dev, requires_grad=True)
+    fd = torch.randn(b, p, k, c0, device=dev, requires_grad=True)
+    fts = torch.randn(b, n, c1, device=dev, requires_grad=True)
+    wd = torch.randn(k, c0 + c1, m, device=dev, requires_grad=True)
+    idx = torch.randint(0, n, (b, p, k), device=dev, dtype=torch.int32)
+    inv = index_inverse(idx, n)
+    go = torch.randn(b, p, (c0 + c1) * m, device=dev)
+    gathered = torch.gather(fts, 1, idx.long().reshape(b, -1, 1).expand(-1, -1, c1)).reshape(b, p, k, c1)
+    fstar = torch.cat([fd, gathered], -1)
+    ref = torch.einsum("bpkc,kcm->bpcm", torch.matmul(x, fstar), wd).reshape(b, p, -1)
+    g_ref = torch.autograd.grad(ref, (x, fd, fts, wd), go, retain_graph=True)          # fstar's graph is used again below
+    for name, out in (("gather", pc.xconv_depthwise_gather(x, fd, fts, idx, wd, inv)), ("dense", pc.xconv_depthwise(x, fstar, wd))):
+        assert "XConvDepthwise" in out.grad_fn.next_functions[0][0].__class__.__name__ + out.grad_fn.__class__.__name__     # the HIP node ran
+        g = torch.autograd.grad(out, (x, fd, fts, wd), go, retain_graph=True)
+        assert float((out.detach() - ref.detach()).abs().max()) <= 1e-4 * float(ref.detach().abs().max()), name
+        for a, r, what in zip(g, g_ref, ("x", "f_delta", "fts", "wd")):
+            assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()), (name, what)
