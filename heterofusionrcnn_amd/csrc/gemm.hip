@@ -1203,6 +1203,34 @@ HF_API int hf_lift_elu_bn_fwd(long long rows, int c0, int c1, const float *x3, c
     return launch_status();
 }
 
+// inference: the first layer normalised with GIVEN statistics (its running estimates), no statistics pass; the second GEMM's batch
+// statistics land in the workspace and are ignored
+HF_API int hf_lift_elu_fwd_eval(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                                const float *mean0, const float *invstd0, const float *w1, float *z1, void *workspace,
+                                size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows <= 0 || c0 <= 0 || c0 > kLiftMaxC || c0 % 4 != 0 || c1 <= 0 || c1 > 256 || !x3 || !w0 || !gamma0 || !beta0 || !mean0 ||
+        !invstd0 || !w1 || !z1 || reinterpret_cast<uintptr_t>(w1) % 16 != 0)
+        return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_lift_elu_bn_fwd_workspace(c0, c1)) return HF_EWORKSPACE;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const long long ntiles = (rows + kFwdRows - 1) / kFwdRows;
+    const int nt = div_up(c1, 32);
+    const int nblk = resident_grid(nt, ntiles);
+#define HF_LIFT_FWD(N)                                                                                                  \
+    case N:                                                                                                             \
+        hipLaunchKernelGGL((lift_linear_fwd_kernel<N>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, c0, c1, ntiles, x3, w0,  \
+                           gamma0, beta0, mean0, invstd0, w1, z1, partial);                                             \
+        break
+    switch (nt) {
+        HF_LIFT_FWD(1); HF_LIFT_FWD(2); HF_LIFT_FWD(3); HF_LIFT_FWD(4); HF_LIFT_FWD(5); HF_LIFT_FWD(6); HF_LIFT_FWD(7); HF_LIFT_FWD(8);
+        default: return HF_EINVAL;
+    }
+#undef HF_LIFT_FWD
+    return launch_status();
+}
+
 HF_API size_t hf_lift_elu_bn_bwd_workspace(long long rows, int c0, int c1)
 {
     if (rows <= 0 || c0 <= 0 || c1 <= 0) return 0;

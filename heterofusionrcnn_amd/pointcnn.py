@@ -170,12 +170,33 @@ class _LiftChain(torch.autograd.Function):
         return None, dw0_t.t(), dg0, db0, dw1, dg1, db1, None, None
 
 
+def _lift_chain_eval(d0, d1, x):
+    """inference twin of _LiftChain on the 3-channel input: the first layer's output is rebuilt from x inside the second GEMM with
+    its RUNNING statistics, the second layer's running statistics are applied by one pass; nothing else is written"""
+    L = _lib.lib()
+    rows = x.numel() // 3
+    bn0, bn1 = d0.post.bn, d1.post.bn
+    c0, c1 = d0.linear.out_features, d1.linear.out_features
+    x2 = x.reshape(rows, 3).contiguous()
+    z1 = torch.empty((rows, c1), dtype=torch.float32, device=x.device)
+    nbytes = L.hf_lift_elu_bn_fwd_workspace(c0, c1)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    w0, w1 = d0.linear.weight.contiguous(), d1.linear.weight.contiguous()
+    check(L.hf_lift_elu_fwd_eval(rows, c0, c1, ptr(x2), ptr(w0), ptr(bn0.weight), ptr(bn0.bias), ptr(bn0.running_mean), ptr(bn0.eval_invstd()),
+                                 ptr(w1), ptr(z1), ptr(ws), nbytes, stream_ptr()), "lift_elu_fwd_eval")
+    return bn1(z1).reshape(*x.shape[:-1], c1)          # eval-mode BatchNormReLU: a (elu(z1) - running_mean) + beta
+
+
 def dense_chain(d0, d1, x):
-    """d1(d0(x)) for two Dense modules; tall training batches on the device take the one-node MFMA route"""
+    """d1(d0(x)) for two Dense modules; tall batches on the device take the one-node MFMA route"""
     from .mlp import FUSED_FWD_MIN_ROWS
     rows = x.numel() // x.shape[-1]
     bn0, bn1 = d0.post.bn, d1.post.bn
     c0, c1 = d0.linear.out_features, d1.linear.out_features
+    if (x.is_cuda and x.dtype == torch.float32 and not bn0.training and not bn1.training and not torch.is_grad_enabled()
+            and d0.post.activation and d1.post.activation and x.shape[-1] == 3 and rows >= FUSED_FWD_MIN_ROWS and c0 <= 256
+            and c0 % 4 == 0 and c1 <= 256):
+        return _lift_chain_eval(d0, d1, x)
     if (x.is_cuda and x.dtype == torch.float32 and bn0.training and bn1.training and d0.post.activation and d1.post.activation
             and rows >= FUSED_FWD_MIN_ROWS and c0 <= 160 and c1 <= 224 and x.shape[-1] <= 1024):
         if x.shape[-1] == 3 and c0 % 4 == 0 and not x.requires_grad:

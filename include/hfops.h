@@ -370,6 +370,11 @@ int hf_lift_elu_bn_fwd(long long rows, int c0, int c1, const float *x3, const fl
                        float eps0, float momentum0, float *running_mean0, float *running_var0, float *mean0, float *invstd0,
                        const float *w1, float *z1, float eps1, float momentum1, float *running_mean1, float *running_var1,
                        float *mean1, float *invstd1, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+/* inference form: the first layer normalised with the GIVEN mean0 / invstd0 (its running estimates), z1 only; workspace as
+ * hf_lift_elu_bn_fwd_workspace */
+int hf_lift_elu_fwd_eval(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                         const float *mean0, const float *invstd0, const float *w1, float *z1, void *workspace, size_t workspace_bytes,
+                         hf_stream_t stream);
 size_t hf_lift_elu_bn_bwd_workspace(long long rows, int c0, int c1);
 int hf_lift_elu_bn_bwd(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
                        const float *mean0, const float *invstd0, const float *dz1, const float *w1_t, float *grad_w0_t,

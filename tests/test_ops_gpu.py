@@ -1755,3 +1755,26 @@ def test_xconv_depthwise_kernels_at_the_rcnn_neighbourhood_sizes(k, m, c0, c1):
         assert float((out.detach() - ref.detach()).abs().max()) <= 1e-4 * float(ref.detach().abs().max()), name
         for a, r, what in zip(g, g_ref, ("x", "f_delta", "fts", "wd")):
             assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()), (name, what)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [64, 128, 256])
+def test_dense_chain_inference_form_equals_layer_by_layer(c):
+    """eval mode: pointcnn.dense_chain on a 3-channel input rebuilds the first layer inside the second GEMM with the RUNNING
+    statistics (hf_lift_elu_fwd_eval); against the two Dense modules run one after the other in eval mode"""
+    from heterofusionrcnn_amd import pointcnn as pc
+    torch.manual_seed(c)
+    rows = 40000
+    d0, d1 = pc.Dense(3, c).cuda(), pc.Dense(c, c).cuda()
+    with torch.no_grad():
+        for d in (d0, d1):
+            d.post.bn.weight.uniform_(0.5, 1.5)
+            d.post.bn.bias.uniform_(-0.5, 0.5)
+            d.post.bn.running_mean.uniform_(-0.3, 0.3)
+            d.post.bn.running_var.uniform_(0.5, 2.0)
+    d0.eval(); d1.eval()
+    x = torch.randn(4, rows // 4, 3, device="cuda")
+    with torch.no_grad():
+        a = pc.dense_chain(d0, d1, x)
+        b = d1(d0(x))
+    assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
