@@ -555,7 +555,6 @@ static int cell_launch(dim3 grid, size_t lds, hipStream_t st, int n, int m, int 
                         float inv_cs, int nsample, int ns_shift, int cap, int stop, const float *xyz1, const float *xyz2,
                         int center, int *idx, int *pts_cnt, float *grouped)
 {
-    static size_t lds_allowed = 0;   // raise the dynamic-LDS limit of this instantiation once, not on every launch
     static int static_lds = -1;
     if (static_lds < 0) {
         hipFuncAttributes fa;
@@ -563,11 +562,8 @@ static int cell_launch(dim3 grid, size_t lds, hipStream_t st, int n, int m, int 
                          ? static_cast<int>(fa.sharedSizeBytes) : 1;
     }
     if (static_lds != 0) return HF_EINVAL;   // lds_u32 assumes the dynamic region starts at LDS address 0
-    if (lds > lds_allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_cell_kernel<GRP, SM, NT, A4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        lds_allowed = 160 * 1024 - 512;
-    }
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&qbp_cell_kernel<GRP, SM, NT, A4>), lds);
+    if (lrc != HF_OK) return lrc;
     hipLaunchKernelGGL((qbp_cell_kernel<GRP, SM, NT, A4>), grid, dim3(NT), lds, st, n, m, qpw, glog, radius, thresh, inv_cs,
                        nsample, ns_shift, cap, stop, xyz1, xyz2, center, idx, pts_cnt, grouped);
     return launch_status();

@@ -525,12 +525,8 @@ template <int PPT, int HB, int S>
 static int build_launch(int b, int n, float inv_cs, const float *xyz1, unsigned char *ws, size_t stride, hipStream_t st)
 {
     const size_t lds = sizeof(unsigned) * ((static_cast<size_t>(1) << HB) / S + 32) + sizeof(float4) * kSortChunk;
-    static bool raised = false;   // raise the dynamic-LDS limit of this instantiation once, not on every launch
-    if (lds > 48 * 1024 && !raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&bq_build_kernel<PPT, HB, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
-        raised = true;
-    }
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&bq_build_kernel<PPT, HB, S>), lds);
+    if (lrc != HF_OK) return lrc;
     // stop: diagnostic builds only (early exit after a phase, outputs invalid); the product passes the constant 0
     hipLaunchKernelGGL((bq_build_kernel<PPT, HB, S>), dim3(b, S), dim3(kSortThreads), lds, st, n, n <= kPackedMaxN ? 1 : 0,
                        HF_DIAG_INT("HF_BQ_STOP", 0), inv_cs, xyz1, ws, stride);
@@ -573,12 +569,8 @@ int launch_ball_query_sorted(int b, int n, int m, float radius, float thresh, in
     const dim3 grid(b, div_up(m, qpw));
 #define HF_BQ_LAUNCH(GRP, GG)                                                                                                     \
     do {                                                                                                                          \
-        static bool raised = false;                                                                                               \
-        if (lds > 48 * 1024 && !raised) {                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&bq_query_kernel<GRP, 1, GG>),                               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);                             \
-            raised = true;                                                                                                        \
-        }                                                                                                                         \
+        const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&bq_query_kernel<GRP, 1, GG>), lds);                    \
+        if (lrc != HF_OK) return lrc;                                                                                             \
         hipLaunchKernelGGL((bq_query_kernel<GRP, 1, GG>), grid, dim3(kQueryThreads), lds, st, n, m, hbits, radius, thresh, inv_cs, \
                            nsample, ns_shift, pshift, xyz1, xyz2, center, ws, stride, idx, pts_cnt, grouped);                     \
     } while (0)

@@ -789,14 +789,9 @@ using namespace hf;
 
 // the pair-tile kernels keep their state (and the clip's point arrays) in dynamic LDS: ~33 KB, four workgroups per CU
 template <typename K>
-static void tile_lds_attr(K kernel, size_t bytes = sizeof(TileShared))
+static int tile_lds_attr(K kernel, size_t bytes = sizeof(TileShared))
 {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(bytes));
-        done = true;
-    }
+    return ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 HF_API int hf_compute_bev_iou(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans_overlap,
@@ -806,7 +801,7 @@ HF_API int hf_compute_bev_iou(int num_a, const float *boxes_a, int num_b, const 
     if (num_a <= 0 || num_b <= 0 || !boxes_a || !boxes_b) return HF_EINVAL;
     if (!ans_overlap && !ans_iou) return HF_OK;
     const int gy = (num_a + kIouRows - 1) / kIouRows, gx = (num_b + 63) / 64;
-    tile_lds_attr(&bev_iou_kernel, sizeof(IouShared));
+    if (const int lrc = tile_lds_attr(&bev_iou_kernel, sizeof(IouShared)); lrc != HF_OK) return lrc;
     const int stop = HF_DIAG_INT("HF_BEV_STOP", 0);   // diagnostic builds only: early exit after a phase (outputs invalid)
     if ((ans_overlap && reinterpret_cast<uintptr_t>(ans_overlap) % 16 != 0) || (ans_iou && reinterpret_cast<uintptr_t>(ans_iou) % 16 != 0))
         return HF_EINVAL;   // the outputs are written with 16-byte stores (every allocator returns at least that alignment)
@@ -833,7 +828,7 @@ HF_API int hf_nms_mask(const float *boxes, unsigned long long *mask, int boxes_n
     if (boxes_num <= 0 || !boxes || !mask) return HF_EINVAL;
     const int cb = (boxes_num + 63) / 64;
     if (cb > 65535) return HF_EINVAL;
-    tile_lds_attr(&nms_mask_kernel<false>);
+    if (const int lrc = tile_lds_attr(&nms_mask_kernel<false>); lrc != HF_OK) return lrc;
     hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(cb, cb), dim3(kNmsThreads), sizeof(TileShared), as_stream(stream), boxes_num,
                        nms_overlap_thresh, boxes, mask, static_cast<size_t>(0));
     return launch_status();
@@ -870,18 +865,14 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
     int rc = hip_status(hipMemset2DAsync(ws + nms_ws_counts_offset(n), ws_stride, 0, sizeof(int) * static_cast<size_t>(cb), frames, st));
     if (rc != HF_OK) return rc;
     hipLaunchKernelGGL(nms_boxpre_kernel, dim3(div_up(n, 256), frames), dim3(256), 0, st, n, boxes, ws, ws_stride);
-    tile_lds_attr(&nms_mask_kernel<true>);
+    if (const int lrc = tile_lds_attr(&nms_mask_kernel<true>); lrc != HF_OK) return lrc;
     hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(cb, cb, frames), dim3(kNmsThreads), sizeof(TileShared), st, n, thresh, boxes,
                        reinterpret_cast<unsigned long long *>(ws), ws_stride);
     rc = launch_status();
     if (rc != HF_OK) return rc;
     if (HF_DIAG_INT("HF_NMS_STOP", 0) == 1) return HF_OK;   // diagnostic builds only: mask kernel alone (keep[] is not written)
-    static size_t sweep_lds_allowed = 48 * 1024;   // raise the dynamic-LDS limit once, not on every launch
-    if (lds > sweep_lds_allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 256);
-        sweep_lds_allowed = 160 * 1024 - 256;
-    }
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&nms_sweep_kernel), lds);
+    if (rc != HF_OK) return rc;
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(frames), dim3(kSweepThreads), lds, st, n, chunk_blocks, ws, ws_stride, keep, num_kept);
     return launch_status();
 }

@@ -192,9 +192,7 @@ HF_API int hf_pc_crop_and_sample(const float *pts, const float *fts, const float
     if (lds > 150 * 1024) return HF_EINVAL;  // resize > ~7600: no config comes close (R = 512)
     const bool al16 = (reinterpret_cast<uintptr_t>(fts) % 16 == 0) && (reinterpret_cast<uintptr_t>(crop_fts) % 16 == 0);
     if ((channel & 3) == 0 && !al16) return HF_EINVAL;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&crop_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&crop_kernel), lds); lrc != HF_OK) return lrc;
     const int grid = num_boxes < kNumCU * 8 ? num_boxes : kNumCU * 8;
     hipLaunchKernelGGL(crop_kernel, dim3(grid), dim3(kCropThreads), lds, as_stream(stream), pts, fts, intensities, mask,
                        boxes, box_ind, num_boxes, npts, resize, channel, intensity_channel, crop_pts, crop_fts,

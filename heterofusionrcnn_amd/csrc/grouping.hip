@@ -439,15 +439,11 @@ static int launch_ball_query_bruteforce(int b, int n, int m, float thresh, int n
     if (lds > 160 * 1024) return HF_EINVAL;  // nsample > ~148: not used by any config
     dim3 grid(div_up(m, kQbThreads), b);
     if (grouped) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_bruteforce_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&qbp_bruteforce_kernel<true>), lds); lrc != HF_OK) return lrc;
         hipLaunchKernelGGL((qbp_bruteforce_kernel<true>), grid, dim3(kQbThreads), lds, st, n, m, thresh, nsample, xyz1,
                            xyz2, center, idx, pts_cnt, grouped);
     } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&qbp_bruteforce_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&qbp_bruteforce_kernel<false>), lds); lrc != HF_OK) return lrc;
         hipLaunchKernelGGL((qbp_bruteforce_kernel<false>), grid, dim3(kQbThreads), lds, st, n, m, thresh, nsample,
                            xyz1, xyz2, center, idx, pts_cnt, grouped);
     }
@@ -877,9 +873,7 @@ HF_API int hf_knn_point(int b, int n, int m, int k, const float *xyz1, const flo
     const long long queries = static_cast<long long>(b) * m;
 #define HF_KNN_LAUNCH(P)                                                                                              \
     do {                                                                                                              \
-        if (lds > 48 * 1024)                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_kernel<P>),                                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));             \
+        if (const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_kernel<P>), lds); lrc != HF_OK) return lrc; \
         hipLaunchKernelGGL((knn_kernel<P>), dim3(div_up(m, kKnnThreads / P), b), dim3(kKnnThreads), lds, st, n, m, k,   \
                            xyz1, xyz2, val, idx);                                                                     \
     } while (0)
@@ -904,9 +898,7 @@ int launch_knn_grid(int b, int n, int m, int k, const float *data, const float *
     if (lds > 150 * 1024 || b > 65535 || reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return HF_EINVAL;  // k <= 75
     const int g = knn_grid_for(n);
     hipLaunchKernelGGL(knn_bin_kernel, dim3(b), dim3(kKnnBinThreads), 0, st, n, g, data, workspace);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
+    if (const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_grid_kernel), lds); lrc != HF_OK) return lrc;
     hipLaunchKernelGGL(knn_grid_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, st, n, m, k, g, queries,
                        workspace, val, idx);
     return launch_status();

@@ -1,8 +1,29 @@
 // hf_api.cpp -- library-level entry points of libhfops.so (version / error text).
 #include "hf_common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace hf {
 thread_local int g_last_hip_error = 0;
+
+int ensure_dynamic_lds(const void *kernel, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return HF_OK;
+    int dev = 0;
+    const hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return hip_status(e0);
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[std::make_pair(dev, kernel)];
+    if (bytes <= have) return HF_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (e != hipSuccess) return hip_status(e);
+    have = bytes;
+    return HF_OK;
+}
 }
 
 HF_API const char *hf_version(void) { return "hfops-mi355x 0.1.0 (gfx950)"; }

@@ -20,6 +20,12 @@ inline int hip_status(hipError_t e)
     return HF_EHIP;
 }
 
+// hf_api.cpp: opt a kernel in to `bytes` of dynamic LDS (> 48 KB needs hipFuncAttributeMaxDynamicSharedMemorySize) ON THE
+// CURRENT DEVICE.  The grant is remembered per (device, kernel): a process that drives several devices raises the limit on
+// each of them, and a launch path pays one hipGetDevice + a table lookup instead of an attribute call.  HF_EHIP if the
+// runtime refuses.  Call it on every launch path whose LDS request can exceed 48 KB.
+int ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 // BatchNorm partial-sum layout shared by mlp.hip and gemm.hip: partial[ch * kBnMaxBlocks + blk] = sum,
 // partial[(c + ch) * kBnMaxBlocks + blk] = sum of squares, blk < nblk <= kBnMaxBlocks
 constexpr int kBnMaxBlocks = 2048;

@@ -436,8 +436,10 @@ HF_API int hf_three_nn_inverse(int b, int n, int m, const int *idx, int *offsets
     if (b < 0 || n < 0 || m <= 0 || m > kInvMaxKnown || !offsets || (n > 0 && (!idx || !entries))) return HF_EINVAL;
     if (b == 0) return HF_OK;
     if (static_cast<long long>(n) * 3 > 0x7fffffffll) return HF_EINVAL;
-    hipLaunchKernelGGL(three_nn_inverse_kernel, dim3(b), dim3(kInvThreads), sizeof(int) * 2 * static_cast<size_t>(m),
-                       as_stream(stream), 3ll * n, m, idx, offsets, entries);
+    const size_t lds = sizeof(int) * 2 * static_cast<size_t>(m);   // m = 8192: 64 KB, above the default limit
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&three_nn_inverse_kernel), lds);
+    if (lrc != HF_OK) return lrc;
+    hipLaunchKernelGGL(three_nn_inverse_kernel, dim3(b), dim3(kInvThreads), lds, as_stream(stream), 3ll * n, m, idx, offsets, entries);
     return launch_status();
 }
 
@@ -447,12 +449,8 @@ HF_API int hf_index_inverse(int b, long long total, int m, const int *idx, int *
         return HF_EINVAL;
     if (b == 0) return HF_OK;
     const size_t lds = sizeof(int) * 2 * static_cast<size_t>(m);
-    static bool raised = false;   // raise the dynamic-LDS limit once, not on every launch
-    if (lds > 48 * 1024 && !raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&three_nn_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 512);
-        raised = true;
-    }
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&three_nn_inverse_kernel), lds);
+    if (lrc != HF_OK) return lrc;
     hipLaunchKernelGGL(three_nn_inverse_kernel, dim3(b), dim3(kInvThreads), lds, as_stream(stream), total, m, idx, offsets, entries);
     return launch_status();
 }

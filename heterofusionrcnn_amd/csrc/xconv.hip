@@ -567,12 +567,8 @@ template <int K>
 static int launch_dx(long long rows, int c, const float *grad_out, const float *f, float *grad_x, hipStream_t st)
 {
     const size_t lds = sizeof(float) * (kXcThreads / 64) * 64 * (K * K + 1);
-    static bool raised = false;
-    if (!raised && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&xconv_dx_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds));
-        raised = true;
-    }
+    const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&xconv_dx_kernel<K>), lds);
+    if (lrc != HF_OK) return lrc;
     hipLaunchKernelGGL((xconv_dx_kernel<K>), dim3(grid_for(rows, kXcThreads / 64)), dim3(kXcThreads), lds, st, rows, c, grad_out, f,
                        grad_x);
     return launch_status();

@@ -132,7 +132,7 @@ def project_boxes_to_image(boxes_3d, calib, image_hw):
     return box, box / torch.tensor([w, h, w, h], dtype=box.dtype, device=box.device)
 
 
-def crop_and_resize(img_fts, boxes_norm_yxyx, box_ind, crop_size, extrapolation_value=0.0):
+def image_crop_and_resize(img_fts, boxes_norm_yxyx, box_ind, crop_size, extrapolation_value=0.0):
     """tf.image.crop_and_resize (bilinear) as the RCNN uses it on the image feature map (rcnn_model.py:494-500): img_fts
     (B,H,W,C), boxes (N,4) [y1,x1,y2,x2] normalised, box_ind (N) -> (N,crop,crop,C).  Sample i of a crop sits at
     y1 (H-1) + i (y2-y1)(H-1)/(crop-1); a sample outside [0, H-1] x [0, W-1] takes the extrapolation value.

@@ -106,7 +106,9 @@ class TrainStep:
       loss = step(geometry=geo)          # inputs are the static tensors given at construction unless passed again
 
     `inputs`: dict with xyz, intensity, label_cls, label_reg and optionally img_fts, calib.  `loss_fn(model, inputs, geometry)`
-    returns the scalar loss (default: RpnModel forward + RpnModel.loss)."""
+    returns the scalar loss (default: RpnModel forward + RpnModel.loss).  Capturing needs `warmup` eager steps first (lazy
+    initialisations, optimizer state); their effect on parameters, buffers and optimizer state is undone before the capture, so
+    the first replay starts from the state the caller handed in -- the same trajectory as graph=False."""
 
     def __init__(self, model, optimizer, inputs, geometry, world=1, graph=True, loss_fn=None, warmup=3):
         self.model, self.opt, self.world = model, optimizer, world
@@ -145,6 +147,11 @@ class TrainStep:
     def _capture(self, warmup):
         # PyTorch's recipe: a few eager iterations on a side stream (lazy initialisations, allocator warm-up, optimizer
         # state), then capture on that stream
+        # The warm-up steps are real steps (Adam, BatchNorm running statistics, with several ranks the all-reduce) on the batch
+        # given at construction; building a TrainStep must not train, so parameters, buffers and optimizer state are put back
+        # IN PLACE afterwards (same storage: the capture below records these addresses).  Only the device generator's offset
+        # stays advanced (dropout / path-drop draws of the warm-up).
+        snap = self._snapshot()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -152,6 +159,7 @@ class TrainStep:
                 self._forward_backward()
                 self._finish()
         torch.cuda.current_stream().wait_stream(s)
+        self._restore(snap)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -162,6 +170,26 @@ class TrainStep:
         # afterwards: with several ranks the parameters adopt the flat views (filled by the captured foreach copy)
         if self.flat_mode:
             self.grads.adopt()
+
+    def _snapshot(self):
+        with torch.no_grad():
+            tensors = [t for t in list(self.model.parameters()) + list(self.model.buffers())]
+            state = {id(t): {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                     for t, st in self.opt.state.items()}
+            return [(t, t.clone()) for t in tensors], state
+
+    def _restore(self, snap):
+        tensors, state = snap
+        with torch.no_grad():
+            if tensors:
+                torch._foreach_copy_([t for t, _ in tensors], [c for _, c in tensors])
+            for t, st in self.opt.state.items():                       # state the warm-up created: back to its initial zeros
+                old = state.get(id(t), {})
+                for k, v in st.items():
+                    if isinstance(v, torch.Tensor):
+                        v.copy_(old[k]) if k in old else v.zero_()
+                    elif k in old:
+                        st[k] = old[k]
 
     # ------------------------------------------------------------------ a step
     def load(self, geometry=None, **inputs):

@@ -13,7 +13,9 @@ def _ball_query(variant, b, n, m, radius, nsample, xyz1, xyz2, center, idx, cnt,
     L = _lib.lib()
     v = BALL_QUERY_VARIANTS[variant]
     ws, nbytes = None, 0
-    if v in (0, 3):
+    # the cell-sorted pair needs a workspace; 'auto' takes it from 32 clouds and more than one round of query tiles only
+    # (launch_ball_query, grouping.hip), so smaller calls do not allocate b * (16 n + 64 KB) bytes for nothing
+    if v == 3 or (v == 0 and b >= 32 and b * ((m + 127) // 128) > 256):
         nbytes = L.hf_ball_query_workspace(b, n)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz1.device)
     check(L.hf_query_ball_group_xyz_ws(v, b, n, m, radius, nsample, ptr(xyz1), ptr(xyz2), 1 if center else 0, ptr(idx), ptr(cnt),
@@ -217,12 +219,12 @@ def select_top_k(k, dist):
     return outi, out
 
 
-def knn_point(k, xyz1, xyz2, all_pairs=False):
+def knn_point(k, xyz1, xyz2, all_pairs=False, dense=False):
     """xyz1 (B,N,C) data, xyz2 (B,M,C) queries -> (val (B,M,k) squared L2 ascending, idx (B,M,k) int32).
     Reference: tf_grouping.py:62-95 (dense |q|^2 - 2 q.p^T + |p|^2 matrix + tf.nn.top_k).  For C == 3 this is
     the HIP kNN kernel (no (B,M,N) matrix; ties: lower index first): data binned into a 2-D grid + ring search for
-    N <= 65536, the tiled all-pairs kernel beyond that or with all_pairs=True.  Other channel counts keep the
-    reference's three-term formula in torch.
+    N <= 65536, the tiled all-pairs kernel beyond that or with all_pairs=True.  Other channel counts or k > 67 RAISE
+    unless dense=True is passed, which takes the reference's three-term formula in framework ops (torch.topk tie order).
     PARITY UNPINNED against the reference where it matters for ties: the reference ranks the fp32 three-term expansion
     with tf.nn.top_k, this kernel ranks (q - p)^2 summed per axis with ties to the lower index.  The neighbour sets agree
     wherever the k-th and (k+1)-th distances differ by more than the rounding of the expansion; the order among exact
@@ -248,6 +250,10 @@ def knn_point(k, xyz1, xyz2, all_pairs=False):
         else:
             check(L.hf_knn_point(b, n, m, k, ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), stream_ptr()), "knn_point")
         return val, idx
+    # No shipped config reaches here (every caller searches 3-D coordinates with k <= 48).  The dense (b,m,n) form is the
+    # reference's own expression in framework ops, with torch.topk's tie order -- never taken silently.
+    require(dense, "knn_point: the HIP kernels cover c == 3 and k <= 67; pass dense=True to take the (b,m,n) "
+                   "distance-matrix form in framework ops (torch.topk tie order, parity unpinned)")
     r1 = (xyz1 * xyz1).sum(dim=2, keepdim=True)              # (b,n,1)
     r2 = (xyz2 * xyz2).sum(dim=2, keepdim=True)              # (b,m,1)
     mul = torch.matmul(xyz2, xyz1.transpose(1, 2))           # (b,m,n)

@@ -78,8 +78,11 @@ class ImgVggPyr(nn.Module):
 
 def load_kitti_frame(dataset_dir, name, rng, num_points=16384, img_hw=(360, 1200)):
     """One frame of <dataset_dir>/{velodyne,calib,image_2}/<name>.* -> dict of numpy arrays: xyz (P,3), intensity (P,1), image
-    (h,w,3) float32 resized as the reference resizes it (kitti_dataset.py:398), calib (3,4) = P2 (NOT rescaled: the reference feeds
-    the original matrix with the resized image), image_size (w, h) of the ORIGINAL image (result boxes are written in its pixels)"""
+    (h,w,3) float32 resized as the reference resizes it (kitti_dataset.py:398), calib (3,4) = P2 RESCALED WITH THE IMAGE as the
+    reference does (kitti_dataset.py:399-400, 525-526: row 0 *= img_w / w0, row 1 *= img_h / h0) -- the matrix the detector
+    projects with (project_gather, project_boxes_to_image, crop_and_resize all work in resized pixels); calib_orig (3,4) = P2 as
+    read, for the result files (boxes are written in ORIGINAL-image pixels, evaluator_utils.py:88-166), image_size (w, h) of the
+    original image"""
     from PIL import Image      # the one image reader of this package: only this file-level flow needs it
     calib = kitti_io.read_calib(os.path.join(dataset_dir, "calib", name + ".txt"))
     img = Image.open(os.path.join(dataset_dir, "image_2", name + ".png")).convert("RGB")
@@ -87,8 +90,17 @@ def load_kitti_frame(dataset_dir, name, rng, num_points=16384, img_hw=(360, 1200
     pts, inten = kitti_io.load_point_cloud(os.path.join(dataset_dir, "velodyne", name + ".bin"), calib, (h0, w0))
     sample, _ = kitti_io.sample_points(pts, inten, num_points, rng)
     image = np.asarray(img.resize((img_hw[1], img_hw[0]), Image.BILINEAR), dtype=np.float32)
+    p2 = calib["p2"].astype(np.float32)
     return {"name": name, "xyz": sample[:, :3].copy(), "intensity": sample[:, 3:4].copy(), "image": image,
-            "calib": calib["p2"].astype(np.float32), "image_size": (w0, h0)}
+            "calib": rescale_p2(p2, (w0, h0), (img_hw[1], img_hw[0])), "calib_orig": p2, "image_size": (w0, h0)}
+
+
+def rescale_p2(p2, size_wh, new_size_wh):
+    """P2 for an image resized from size_wh to new_size_wh: u' = u * w'/w, v' = v * h'/h (kitti_dataset.py:399-400)"""
+    out = np.array(p2, dtype=np.float32, copy=True)
+    out[0, :] *= np.float32(new_size_wh[0] / size_wh[0])
+    out[1, :] *= np.float32(new_size_wh[1] / size_wh[1])
+    return out
 
 
 def project_box3d_to_image(box_3d, p2, image_size):
@@ -158,7 +170,7 @@ def run_kitti_inference(detector, img_net, dataset_dir, names, out_dir, ctx, fra
         img_fts = img_net(dev["image"])
         dets = detector(dev["xyz"], dev["intensity"], img_fts, dev["calib"], geometry=geo)
         for f, det in zip(frames, dets):
-            written[f["name"]] = write_frame_results(os.path.join(out_dir, f["name"] + ".txt"), det, f["calib"], f["image_size"],
+            written[f["name"]] = write_frame_results(os.path.join(out_dir, f["name"] + ".txt"), det, f["calib_orig"], f["image_size"],
                                                      score_threshold)
     gathered = dp.gather_objects(written, ctx)
     if ctx.rank != 0:

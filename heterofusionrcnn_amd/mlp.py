@@ -22,9 +22,19 @@ def _workspace(rows, c, device):
     return torch.empty((nbytes // 4,), dtype=torch.float32, device=device), nbytes
 
 
+# The training kernels update running_mean / running_var through raw pointers, which bumps no tensor version: every launch
+# site that hands those pointers to a kernel calls running_stats_written(), and BatchNormReLU.eval_invstd keys its cache on it.
+_STATS_GENERATION = [0]
+
+
+def running_stats_written():
+    _STATS_GENERATION[0] += 1
+
+
 class _BNReLUTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        running_stats_written()          # the kernel below writes the running statistics through raw pointers
         rows, c = x.shape
         y = torch.empty_like(x)
         mean = torch.empty((c,), dtype=torch.float32, device=x.device)
@@ -180,6 +190,8 @@ def linear_bn_fwd(x, weight, bias, bn, in_bn=None, keep_act=False, update_runnin
     applied on load; keep_act also stores that activated input (x_act, else None); update_running=False leaves the
     running estimates alone (inference: the returned batch statistics are then simply not used)."""
     _on_gpu(x, weight, bias)
+    if update_running:
+        running_stats_written()
     rows, cin = x.shape
     cout = weight.shape[0]
     L = _lib.lib()
@@ -221,6 +233,7 @@ def _bn_apply(z, gamma, beta, mean, invstd):
 
 
 def _bn_stats(z, bn):
+    running_stats_written()
     rows, c = z.shape
     mean = torch.empty((c,), dtype=torch.float32, device=z.device)
     invstd = torch.empty((c,), dtype=torch.float32, device=z.device)
@@ -412,6 +425,7 @@ class _LinearBNReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        running_stats_written()          # the kernel below writes the running statistics through raw pointers
         rows, cout = x.shape[0], weight.shape[0]
         z = torch.addmm(bias, x, weight.t())
         y = torch.empty_like(z)
@@ -466,17 +480,21 @@ class BatchNormReLU(nn.Module):
         self.bias = nn.Parameter(torch.zeros(num_features))    # beta: 0
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
-        self._eval_invstd = None      # (version of running_var, device, 1/sqrt(running_var + eps)): inference reuses it
+        self._eval_invstd = None      # (key, 1/sqrt(running_var + eps)): inference reuses it
 
     def train(self, mode=True):
-        self._eval_invstd = None      # the training kernels update running_var through its pointer: no version bump
+        self._eval_invstd = None
         return super().train(mode)
 
     def eval_invstd(self):
         """1/sqrt(running_var + eps), kept between inference calls (two tiny kernels per layer and batch otherwise: 1800 launches
-        per batch of the two-stage inference); dropped on every train() / eval() switch and when running_var is written"""
+        per batch of the two-stage inference).  The key holds the tensor version (framework writes), the package-wide
+        generation counter (raw-pointer writes of the training kernels: running_stats_written) and the storage; nothing is cached while a stream
+        capture is running (the graph's pool memory is reused afterwards)."""
         rv = self.running_var
-        key = (rv._version, rv.device, rv.data_ptr())
+        if torch.cuda.is_current_stream_capturing():
+            return torch.rsqrt(rv + self.eps)
+        key = (rv._version, _STATS_GENERATION[0], rv.device, rv.data_ptr())
         if self._eval_invstd is None or self._eval_invstd[0] != key:
             self._eval_invstd = (key, torch.rsqrt(rv + self.eps))
         return self._eval_invstd[1]
@@ -505,6 +523,7 @@ class _LinearBNReLUMaxPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, k):
+        running_stats_written()          # the kernel below writes the running statistics through raw pointers
         rows, cout = x.shape[0], weight.shape[0]
         groups = rows // k
         z = torch.addmm(bias, x, weight.t())

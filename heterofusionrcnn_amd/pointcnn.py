@@ -32,7 +32,7 @@ from . import _lib
 from ._lib import check, ptr, require, stream_ptr
 from .grouping import INVERSE_MAX_TARGETS, concat_group, group_point, index_inverse, knn_point
 from .sampling import farthest_point_sample, gather_point
-from .mlp import BatchNormReLU, linear_nobias
+from .mlp import BatchNormReLU, linear_nobias, running_stats_written
 
 
 class EluBN(nn.Module):
@@ -78,6 +78,7 @@ class _DenseChainElu(torch.autograd.Function):
         dev = x.device
 
         def layer(inp, w, bn, in_bn, want_act):
+            running_stats_written()
             cout, cin = w.shape
             nbytes = L.hf_linear_bn_fwd_workspace(cout)
             ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
@@ -132,6 +133,7 @@ class _LiftChain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w0, g0, b0, w1, g1, b1, bn0, bn1):
+        running_stats_written()
         L = _lib.lib()
         rows, c0, c1, dev = x.shape[0], w0.shape[0], w1.shape[0], x.device
         w0, w1 = w0.contiguous(), w1.contiguous()
@@ -225,6 +227,7 @@ class _BNConcatGroup(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, mode, points, idx, offsets, entries):
+        running_stats_written()          # the kernel below writes the running statistics through raw pointers
         L = _lib.lib()
         b, n, c = points.shape
         _, m, ns = idx.shape
@@ -272,6 +275,7 @@ class _BNConcatSkip(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, mode, skip):
+        running_stats_written()          # the kernel below writes the running statistics through raw pointers
         L = _lib.lib()
         rows, c = z.shape
         cs = skip.shape[1]

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from . import box_codec, modules
 from .cropping import pc_crop_and_sample
-from .fusion import crop_and_resize, path_drop_masks, project_boxes_to_image
+from .fusion import image_crop_and_resize, path_drop_masks, project_boxes_to_image
 from .pointcnn import Dense, PointCnnBackbone, PointCnnConfig
 
 
@@ -157,7 +157,7 @@ class RcnnModel(nn.Module):
         boxes8 = modules.box_3d_to_box_8co(expand_proposals(flat, cfg.pooling_context_length)).contiguous()
         crop_pts, crop_fts, crop_int, crop_mask, crop_ind, non_empty = pc_crop_and_sample(
             xyz, rpn_fts.contiguous(), intensity, fg_mask, boxes8, box_ind, cfg.roi_crop_size)
-        img_rois = crop_and_resize(img_fts, yxyx, box_ind, cfg.roi_img_crop_size)            # (N,7,7,C1)
+        img_rois = image_crop_and_resize(img_fts, yxyx, box_ind, cfg.roi_img_crop_size)            # (N,7,7,C1)
         return {"flat": flat, "box_ind": box_ind, "crop_pts": crop_pts, "crop_fts": crop_fts, "crop_int": crop_int,
                 "crop_mask": crop_mask, "crop_ind": crop_ind, "non_empty": non_empty, "img_rois": img_rois, "boxes8": boxes8,
                 "yxyx": yxyx}

@@ -265,6 +265,7 @@ _REF_QBP = "_Z20query_ball_point_cpuiiifiPKfS0_Pi"
 _REF_GROUP = "_Z15group_point_cpuiiiiiPKfPKiPf"
 _REF_GROUP_GRAD = "_Z20group_point_grad_cpuiiiiiPKfPKiPf"
 _REF_SELSORT = "_Z18selection_sort_cpuiiiiPKfPiPf"
+_REF_THREENN = "_Z11threenn_cpuiiiPKfS0_PfPi"           # interpolate/interpolate.cpp:21
 _REF_ITP = "_Z15interpolate_cpuiiiiPKfPKiS0_Pf"
 _REF_ITP_GRAD = "_Z20interpolate_grad_cpuiiiiPKfPKiS0_Pf"
 
@@ -304,6 +305,22 @@ def ref_select_top_k(k, dist):
     out = np.empty((b, m, n), np.float32)
     getattr(ref_lib("sel"), _REF_SELSORT)(b, n, m, k, _p(dist), _p(outi), _p(out))
     return outi, out
+
+
+def ref_threenn_origin(known, n=1):
+    """the reference's threenn_cpu (interpolate/interpolate.cpp:21-64) on known (b,m,3) -> (dist (b,n,3), idx (b,n,3)).
+    That function ranks x2*x2 + y2*y2 + z2*z2 -- the squared distance to the ORIGIN, whatever xyz1 holds (its subtraction is
+    commented out, :34-35) -- so it is no general three_nn, but for an unknown point at the origin it is the same fp32
+    expression as tf_interpolate_g.cu:47 ((0-x)*(0-x) == x*x exactly) walked by the same double-1e40 strict-'<' cascade:
+    it pins the cascade, the tie order, the sentinels and the m < 3 case to reference-compiled code.  Every one of the n
+    rows of a batch element is that one answer."""
+    known = _f(known)
+    b, m, _ = known.shape
+    xyz1 = np.zeros((b, n, 3), np.float32)
+    dist = np.empty((b, n, 3), np.float32)
+    idx = np.empty((b, n, 3), np.int32)
+    getattr(ref_lib("itp"), _REF_THREENN)(b, n, m, _p(xyz1), _p(known), _p(dist), _p(idx))
+    return dist, idx
 
 
 def ref_three_interpolate(points, idx, weight):

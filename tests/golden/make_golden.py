@@ -87,7 +87,43 @@ def nms_margin_ok(bev, thresh, margin=1e-4):
     return not np.any(np.abs(iou - thresh) < margin)
 
 
+def threenn_cases():
+    """clouds that walk every branch of the three_nn cascade: random (all three branches, many times), exact duplicates and
+    mirrored points (equal distances: tie order), fewer than three known points (sentinels), descending / ascending order"""
+    rng = np.random.default_rng(21)
+    cases = {"random": rng.standard_normal((4, 500, 3)).astype(np.float32),
+             "large": rng.standard_normal((1, 6000, 3)).astype(np.float32) * 40}
+    dup = rng.standard_normal((3, 60, 3)).astype(np.float32)
+    dup[:, 20:40] = dup[:, :20]                               # exact duplicates at a higher index
+    dup[:, 40:60] = -dup[:, :20]                              # mirrored: the same x*x+y*y+z*z bits
+    cases["ties"] = dup
+    cases["lattice"] = rng.integers(-3, 4, (2, 400, 3)).astype(np.float32)   # distances collide everywhere
+    for m in (1, 2, 3):
+        cases["m%d" % m] = rng.standard_normal((5, m, 3)).astype(np.float32)
+    ramp = np.zeros((2, 64, 3), np.float32)
+    ramp[0, :, 0] = np.arange(64, 0, -1)                      # strictly descending: always the first branch
+    ramp[1, :, 1] = np.arange(1, 65)                          # strictly ascending: branches 1, 2, 3 once, then none
+    cases["ramps"] = ramp
+    cases["all_equal"] = np.ones((1, 17, 3), np.float32)
+    return cases
+
+
+def three_nn_origin():
+    """three_nn_origin.npz: OUTPUTS OF THE REFERENCE's compiled threenn_cpu (interpolate/interpolate.cpp:21-64 through
+    oracle/_ref/libhfref_itp.so) for unknown points at the origin, with the known clouds they belong to."""
+    assert oracle.ref_available("itp"), "needs oracle/_ref/libhfref_itp.so (make -C oracle, with /root/reference present)"
+    arrays = {}
+    for name, known in threenn_cases().items():
+        rd, ri = oracle.ref_threenn_origin(known)
+        od, oi = oracle.three_nn(np.zeros((known.shape[0], 1, 3), np.float32), known)
+        assert np.array_equal(oi, ri) and np.array_equal(od.view(np.uint32), rd.view(np.uint32)), name
+        arrays[name + "_known"], arrays[name + "_dist"], arrays[name + "_idx"] = known, rd, ri
+    save("three_nn_origin", **arrays)
+
+
 def main():
+    if sys.argv[1:] == ["three_nn_origin"]:                  # one fixture on its own (the others stay byte-identical)
+        return three_nn_origin()
     have_ref = all(oracle.ref_available(k) for k in ("qbp", "sel", "itp"))
     print("reference CPU builds available:", have_ref)
 
@@ -237,6 +273,8 @@ def main():
     save("crop", pts=pts, fts=fts, intensities=inten, mask=mask, boxes3d=b3, boxes=boxes, box_ind=box_ind,
          grad_crop_fts=gcf, grad_fts=gf, demo_pts=dp, demo_box=dbox, demo_crop_ind=dres[4], demo_non_empty=dres[5],
          **dict(zip(names, res)))
+    if have_ref:
+        three_nn_origin()
 
 
 if __name__ == "__main__":

@@ -165,9 +165,8 @@ def test_graph_replay_reproduces_the_eager_trajectory():
         opt = torch.optim.Adam(model.parameters(), lr=2e-3, fused=True, capturable=True)
         geo = model.geometry(inp["xyz"])
         step = TrainStep(model, opt, inp, geo, world=1, graph=(mode == "graph"), warmup=0 if mode == "eager" else 3)
-        if mode == "eager":                                   # the graph constructor trains 3 warm-up steps: do the same here
-            for _ in range(3):
-                step(geometry=geo)
+        # the graph constructor's 3 warm-up steps are undone before the capture (parameters, BatchNorm buffers, Adam state):
+        # both modes start from the seeded initial state, the eager loop runs no extra steps
         losses[mode] = [float(step(geometry=geo)) for _ in range(20)]
         if mode == "graph":
             assert step.graph is not None and step.opt_in_graph

@@ -68,14 +68,40 @@ def test_frame_loader_and_result_writer_on_synthetic_files(tmp_path):
     assert f["xyz"].shape == (16384, 3) and f["intensity"].shape == (16384, 1) and f["image"].shape == (360, 1200, 3)
     assert f["calib"].shape == (3, 4) and f["image_size"] == (1242, 375)
     assert -0.5 <= f["intensity"].min() and f["intensity"].max() <= 0.5
-    uv = kitti_io.project_to_image(f["xyz"], f["calib"])
+    uv = kitti_io.project_to_image(f["xyz"], f["calib_orig"])
     assert (uv[:, 0] > 0).all() and (uv[:, 0] < 1242).all() and (uv[:, 1] > 0).all() and (uv[:, 1] < 375).all() and (f["xyz"][:, 2] > 0).all()
+    # the detector's matrix is P2 rescaled with the image (kitti_dataset.py:399-400): a point whose original pixel is (u, v)
+    # lands on (u * 1200/1242, v * 360/375) of the resized map
+    uv_r = kitti_io.project_to_image(f["xyz"], f["calib"])
+    assert np.allclose(uv_r[:, 0], uv[:, 0] * (1200 / 1242), atol=2e-2) and np.allclose(uv_r[:, 1], uv[:, 1] * (360 / 375), atol=2e-2)
+    assert np.array_equal(f["calib"][2], f["calib_orig"][2]) and not np.array_equal(f["calib"][0], f["calib_orig"][0])
     det = {"boxes": np.array([[2.0, 1.6, 20.0, 3.9, 1.6, 1.5, 0.3], [60.0, 1.6, 20.0, 3.9, 1.6, 1.5, 0.0], [1.0, 1.6, 30.0, 0.8, 0.6, 1.7, 0.1]]),
            "scores": np.array([0.9, 0.8, 0.05]), "classes": np.array([1, 1, 2])}
     out = str(tmp_path / "000007.txt")
-    assert INF.write_frame_results(out, det, f["calib"], f["image_size"]) == 1           # one outside the image, one below the threshold
+    assert INF.write_frame_results(out, det, f["calib_orig"], f["image_size"]) == 1           # one outside the image, one below the threshold
     line = open(out).read().split()
     assert line[0] == "Car" and len(line) == 16 and float(line[-1]) == 0.9 and float(line[3]) == -10.0
+
+
+@pytest.mark.gpu
+def test_loaded_frame_gathers_image_features_at_the_rescaled_pixel(tmp_path):
+    """with the resized 360 x 1200 image the fusion must read pixel (u * sx, v * sy); the feature map here
+    holds its own pixel coordinates, so the gathered rows say which pixel every point read"""
+    from heterofusionrcnn_amd import fusion
+    rng = np.random.default_rng(9)
+    root = str(tmp_path / "kitti")
+    _write_frame(root, "000001", rng)
+    f = INF.load_kitti_frame(root, "000001", np.random.default_rng(0))
+    vv, uu = np.meshgrid(np.arange(360, dtype=np.float32), np.arange(1200, dtype=np.float32), indexing="ij")
+    fmap = torch.from_numpy(np.stack([uu, vv], -1)[None]).cuda()                       # (1,360,1200,2): [u, v] of the pixel
+    got = fusion.project_gather(torch.from_numpy(f["xyz"][None]).cuda(), torch.from_numpy(f["calib"][None]).cuda(), fmap)[0].cpu().numpy()
+    uv0 = kitti_io.project_to_image(f["xyz"], f["calib_orig"])                          # original-image pixels
+    want = np.stack([uv0[:, 0] * (1200 / 1242), uv0[:, 1] * (360 / 375)], 1)
+    inside = (want[:, 0] > 1) & (want[:, 0] < 1198) & (want[:, 1] > 1) & (want[:, 1] < 358)
+    assert inside.sum() > 10000
+    assert (np.abs(got[inside] - want[inside]) <= 1.0).all()                            # the integer cast of the scaled pixel
+    wrong = np.abs(got[inside, 0] - uv0[inside, 0])                                     # what the unscaled matrix would read
+    assert wrong.max() > 10
 
 
 @pytest.mark.gpu

@@ -297,6 +297,41 @@ def test_oracle_three_nn(hf, oracle_mod, b, n, m):
     assert np.array_equal(host(dist), od)
 
 
+def test_three_nn_against_reference_cpu_outputs_at_the_origin(hf):
+    """tests/golden/three_nn_origin.npz = outputs of the reference's compiled threenn_cpu (interpolate/interpolate.cpp:21-64;
+    made by tests/golden/make_golden.py) for unknown points at the origin, where its x2*x2+y2*y2+z2*z2 is the fp32 expression
+    of tf_interpolate_g.cu:47.  Both HIP kernels (grid ring search and all-pairs scan) must give those bits: cascade, tie
+    order among duplicated / mirrored / lattice points, +inf / index 0 when fewer than three points are known."""
+    from heterofusionrcnn_amd.interpolate import three_nn_all_pairs
+    g = load_golden("three_nn_origin")
+    names = [k[:-6] for k in g if k.endswith("_known")]
+    assert len(names) == 9
+    for name in names:
+        known = g[name + "_known"]
+        u = np.zeros((known.shape[0], 5, 3), np.float32)
+        for fn in (hf.three_nn, three_nn_all_pairs):
+            dist, idx = fn(dev(u), dev(known))
+            for row in range(5):
+                assert np.array_equal(host(idx)[:, row], g[name + "_idx"][:, 0]), (name, fn.__name__)
+                assert np.array_equal(host(dist)[:, row].view(np.uint32), g[name + "_dist"][:, 0].view(np.uint32)), (name, fn.__name__)
+
+
+def test_three_nn_translated_lattice_against_reference_cpu(hf, oracle_mod):
+    """where u - x is exact (dyadic lattice) the reference expression on (u, known) has the bits of threenn_cpu on the cloud
+    translated by -u: the HIP kernels against reference-compiled code with a NON-zero query (tests/test_oracle.py has the
+    oracle's twin).  Needs oracle/_ref (travels with the snapshot)."""
+    from heterofusionrcnn_amd.interpolate import three_nn_all_pairs
+    if not oracle_mod.ref_available("itp"):
+        pytest.skip("oracle/_ref/libhfref_itp.so not built")
+    rng = np.random.default_rng(23)
+    known = (rng.integers(-2048, 2048, (700, 3)) / 64.0).astype(np.float32)
+    unknown = (rng.integers(-2048, 2048, (512, 3)) / 64.0).astype(np.float32)
+    rd, ri = oracle_mod.ref_threenn_origin((unknown[:, None, :] - known[None, :, :]).astype(np.float32))
+    for fn in (hf.three_nn, three_nn_all_pairs):
+        dist, idx = fn(dev(unknown[None]), dev(known[None]))
+        assert np.array_equal(host(idx)[0], ri[:, 0]) and np.array_equal(host(dist)[0].view(np.uint32), rd[:, 0].view(np.uint32))
+
+
 @pytest.mark.parametrize("kind", ["lattice", "same_x", "clustered", "two_known", "nonfinite", "max_lds", "beyond_lds"])
 def test_three_nn_sorted_sweep_matches_all_pairs_scan(hf, oracle_mod, kind):
     """hf.three_nn bins the known points into a 2-D grid and searches rings of cells (the k = 3 case of the kNN
@@ -480,18 +515,35 @@ def _clustered(rng, clusters, copies):
     return boxes[rng.permutation(len(boxes))].astype(np.float32)
 
 
+def _drop_borderline(hf, boxes, thresh, margin=3e-5):
+    """fixture with a margin: one box of every pair whose IoU lies within `margin` of the threshold goes (device and host IoUs
+    agree to 1e-5), so a keep vector can be compared with the oracle's unconditionally"""
+    import oracle
+    _, iou = hf.compute_bev_iou(dev(boxes), dev(boxes))
+    iou = host(iou)
+    _, oiou = oracle.compute_bev_iou(boxes, boxes)
+    near = (np.abs(iou - thresh) < margin) | (np.abs(oiou - thresh) < margin)
+    near &= ~((iou == 0) & (oiou == 0))                          # disjoint on both sides: exact zeros, nothing borderline
+    drop = set()
+    for i, j in np.argwhere(np.triu(near, 1)):
+        if i not in drop and j not in drop:
+            drop.add(int(j))
+    return np.ascontiguousarray(np.delete(boxes, sorted(drop), axis=0))
+
+
 @pytest.mark.parametrize("n,thresh", [(1, 0.5), (64, 0.7), (65, 0.0), (1000, 0.8), (1500, 0.01)])
 def test_oracle_nms(hf, oracle_mod, n, thresh):
     rng = np.random.default_rng(n)
     boxes = _clustered(rng, max(1, n // 10), 10)[:n]
+    if n in (64, 65):                                            # keep the word-boundary sizes exact after the margin pass
+        boxes = _drop_borderline(hf, _clustered(rng, 10, 10), thresh)[:n]
+        assert len(boxes) == n
+    else:
+        boxes = _drop_borderline(hf, boxes, thresh)
+        assert len(boxes) >= n - n // 20
     keep, num = hf.oriented_nms(dev(boxes), thresh, return_count=True)
     ok, okept = oracle_mod.oriented_nms(boxes, thresh, return_count=True)
-    got = host(keep)
-    if not np.array_equal(got, ok):
-        # a flipped decision is only acceptable if some IoU sits within 1e-5 of the threshold
-        _, iou = oracle_mod.compute_bev_iou(boxes, boxes)
-        assert np.any(np.abs(iou - thresh) < TOL), "keep differs without a borderline IoU"
-        pytest.skip("borderline IoU within 1e-5 of the threshold in this random case")
+    assert np.array_equal(host(keep), ok), "keep differs (no IoU of this fixture is within 3e-5 of the threshold)"
     assert int(host(num)[0]) == okept
     # the raw mask, every tile (drop-in for oriented_nms_gpu)
     mask = host(hf.nms_mask(dev(boxes), thresh)).view(np.uint64)

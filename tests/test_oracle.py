@@ -219,3 +219,55 @@ def test_oracle_vs_reference_cpu_interpolate(oracle_mod):
     go = rng.standard_normal((b, n, c)).astype(np.float32)
     assert np.array_equal(oracle_mod.three_interpolate_grad(pts.shape, idx, w, go),
                           oracle_mod.ref_three_interpolate_grad(pts.shape, idx, w, go))
+
+
+def _threenn_cases():
+    g = load_golden("three_nn_origin")
+    return {k[:-6]: g[k] for k in g if k.endswith("_known")}, g
+
+
+def test_oracle_three_nn_vs_reference_cpu_at_the_origin(oracle_mod):
+    """a5 pin: oracle.three_nn (restating tf_interpolate_g.cu:22-65, unbuildable here) against the reference's compiled
+    threenn_cpu for unknown points at the origin -- bit-for-bit, distances and indices (see oracle.ref_threenn_origin)."""
+    _need_ref(oracle_mod, "itp")
+    cases, _ = _threenn_cases()
+    assert set(cases) == {"random", "large", "ties", "lattice", "m1", "m2", "m3", "ramps", "all_equal"}
+    for name, known in cases.items():
+        b, m, _ = known.shape
+        rd, ri = oracle_mod.ref_threenn_origin(known, n=2)
+        od, oi = oracle_mod.three_nn(np.zeros((b, 2, 3), np.float32), known)
+        assert np.array_equal(oi, ri), name
+        assert np.array_equal(od.view(np.uint32), rd.view(np.uint32)), name
+        if m < 3:                                             # sentinels: double 1e40 -> +inf in fp32, index 0
+            assert np.isinf(rd[:, :, m:]).all() and (ri[:, :, m:] == 0).all(), name
+
+
+def test_oracle_three_nn_golden_from_reference_cpu(oracle_mod):
+    """the same pin as committed data (tests/golden/three_nn_origin.npz holds threenn_cpu's outputs): runs where the
+    reference build is absent too"""
+    cases, g = _threenn_cases()
+    for name, known in cases.items():
+        od, oi = oracle_mod.three_nn(np.zeros((known.shape[0], 1, 3), np.float32), known)
+        assert np.array_equal(oi, g[name + "_idx"]), name
+        assert np.array_equal(od.view(np.uint32), g[name + "_dist"].view(np.uint32)), name
+    # duplicates: among equal distances the LOWER index must come first (strict '<')
+    d, i = g["ties_dist"][:, 0], g["ties_idx"][:, 0]
+    for r in range(len(d)):
+        for s_ in range(2):
+            if d[r, s_] == d[r, s_ + 1]:
+                assert i[r, s_] < i[r, s_ + 1]
+
+
+def test_oracle_three_nn_translated_lattice_vs_reference_cpu(oracle_mod):
+    """The subtraction of tf_interpolate_g.cu:47 against reference-compiled code where it is exact: on a dyadic lattice
+    (multiples of 2^-6 below 64) ux - x is representable, so the reference's d for (u, known) has the bits of threenn_cpu's
+    x2*x2+y2*y2+z2*z2 on the cloud translated by -u.  One batch element per query (threenn_cpu advances both clouds per batch)."""
+    _need_ref(oracle_mod, "itp")
+    rng = np.random.default_rng(22)
+    known = (rng.integers(-2048, 2048, (300, 3)) / 64.0).astype(np.float32)
+    unknown = (rng.integers(-2048, 2048, (128, 3)) / 64.0).astype(np.float32)
+    shifted = (known[None, :, :] - unknown[:, None, :]).astype(np.float32)         # exact
+    assert np.array_equal(shifted.astype(np.float64), known[None].astype(np.float64) - unknown[:, None].astype(np.float64))
+    rd, ri = oracle_mod.ref_threenn_origin(-shifted)                               # (u - x): the sign the kernel squares
+    od, oi = oracle_mod.three_nn(unknown[None], known[None])
+    assert np.array_equal(oi[0], ri[:, 0]) and np.array_equal(od[0].view(np.uint32), rd[:, 0].view(np.uint32))

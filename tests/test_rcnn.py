@@ -33,12 +33,12 @@ def test_rcnn_config_numbers_and_wiring():
     assert m.mlp.layers[0].linear.in_features == 6
 
 
-def test_crop_and_resize_against_a_loop():
+def test_image_crop_and_resize_against_a_loop():
     rng = np.random.default_rng(0)
     img = rng.standard_normal((2, 9, 13, 3)).astype(np.float32)
     boxes = np.array([[0.1, 0.2, 0.8, 0.9], [0.0, 0.0, 1.0, 1.0], [-0.2, 0.3, 0.5, 1.3], [0.4, 0.4, 0.4, 0.4], [0.9, 0.1, 0.2, 0.7]], np.float32)
     ind = np.array([0, 1, 1, 0, 1], np.int32)
-    got = fusion.crop_and_resize(torch.from_numpy(img), torch.from_numpy(boxes), torch.from_numpy(ind), 4).numpy()
+    got = fusion.image_crop_and_resize(torch.from_numpy(img), torch.from_numpy(boxes), torch.from_numpy(ind), 4).numpy()
     h, w, crop = 9, 13, 4
     want = np.zeros((5, crop, crop, 3), np.float32)
     for n, (y1, x1, y2, x2) in enumerate(boxes):
