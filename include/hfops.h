@@ -512,6 +512,26 @@ int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, int k, 
                                    float *grad_f_delta, float *grad_fts, float *grad_wd, void *workspace, size_t workspace_bytes,
                                    hf_stream_t stream);
 
+/* ------------------------------------------------------------------ the optimizer step of the train step */
+
+/* tf.train.AdamOptimizer.apply_gradients over EVERY parameter tensor in one launch (hf/core/trainer.py:71,
+ * hf/builders/optimizer_builder.py:59-64; the framework form is one multi-tensor launch per 4 KB of kernel arguments).
+ * table: one entry per tensor, ON THE DEVICE; chunk_map: num_chunks pairs (tensor, chunk) of hf_adam_chunk() elements each,
+ * on the device; step: one float on the device = the number of THIS step (1 for the first; the caller advances it);
+ * grad_scale multiplies every gradient on load (1 / world after a summing all-reduce).
+ * mode 0: p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)   (TensorFlow's placement of epsilon)
+ * mode 1: p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)  (torch.optim.Adam's) */
+typedef struct hf_adam_entry {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    long long numel;
+} hf_adam_entry;
+int hf_adam_chunk(void);
+int hf_adam_multi(int num_chunks, const hf_adam_entry *table, const int *chunk_map, const float *step, float lr, float beta1,
+                  float beta2, float eps, float grad_scale, int mode, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/../../heterofusionrcnn_amd/csrc"
 mkdir -p build_diag
-for f in hf_api.cpp sampling.hip grouping.hip ballquery.hip ballquery_sorted.hip interpolate.hip bev_iou.hip cropping.hip mlp.hip gemm.hip glue.hip xconv.hip; do
+for f in hf_api.cpp sampling.hip grouping.hip ballquery.hip ballquery_sorted.hip interpolate.hip bev_iou.hip cropping.hip mlp.hip gemm.hip glue.hip xconv.hip optim.hip; do
     o=build_diag/${f%.*}.o
     if [ ! -f $o ] || [ $f -nt $o ] || [ hf_common.h -nt $o ] || [ bq_common.h -nt $o ]; then
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -fvisibility=hidden -std=c++17 -I../../include -DHF_DIAG ${HF_DIAG_EXTRA} -x hip -c $f -o $o &

@@ -99,7 +99,8 @@ def test_loaded_frame_gathers_image_features_at_the_rescaled_pixel(tmp_path):
     want = np.stack([uv0[:, 0] * (1200 / 1242), uv0[:, 1] * (360 / 375)], 1)
     inside = (want[:, 0] > 1) & (want[:, 0] < 1198) & (want[:, 1] > 1) & (want[:, 1] < 358)
     assert inside.sum() > 10000
-    assert (np.abs(got[inside] - want[inside]) <= 1.0).all()                            # the integer cast of the scaled pixel
+    d = want[inside] - got[inside]                                                      # the integer cast of the scaled pixel
+    assert (d > -2e-2).all() and (d < 1.0 + 2e-2).all()                                 # (fp32 projection on the device, fp64 here)
     wrong = np.abs(got[inside, 0] - uv0[inside, 0])                                     # what the unscaled matrix would read
     assert wrong.max() > 10
 
