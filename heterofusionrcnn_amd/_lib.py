@@ -77,6 +77,11 @@ _SIGNATURES = {
     "hf_linear_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
                          _vp, _sz, _vp],
     "hf_bn_relu_bwd_dx": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "hf_linear_bn_fwd_gather": [ctypes.c_longlong, _i, _i, _vp, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
+                                _vp, _sz, _vp],
+    "hf_linear_wgrad_gather": [ctypes.c_longlong, _i, _i, _vp, _vp, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_adam_chunk": [],
+    "hf_adam_multi": [_i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp],
     "hf_linear_bn_bwd_workspace": [_i],
     "hf_linear_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 18 + [_vp, _sz, _vp],
     "hf_linear_elu_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp],

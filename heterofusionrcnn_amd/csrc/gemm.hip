@@ -52,6 +52,46 @@ __device__ __forceinline__ float4 load4_guarded(const float *__restrict__ base, 
     }
 }
 
+// The first layer of a set-abstraction MLP reads NEIGHBOURHOODS: row r = (cloud, query, slot) of the grouped tensor
+// [points[cloud, idx[r], :] | grouped_xyz[r, :]] that sample_and_group builds (pointnet_util.py:42-64) and the first
+// tf_util.conv2d reads back.  With a GatherSrc the operand is assembled from its two sources while it is staged, so that
+// (B, M, K, C+3) tensor never exists.  Column layout of the assembled operand (the caller permutes the
+// weight's columns to match): [features 0..cf-1, zero-padded to cfp (a multiple of 4) | x, y, z, 0]  ->  cin = cfp + 4.
+struct GatherSrc {
+    const float *points;        // (B, n_src, cf); unused when cf == 0
+    const int *idx;             // (rows) = flattened (B, M, K) neighbour table
+    const float *gxyz;          // (rows, 3) coordinates relative to the query (query_ball_group's third output)
+    int cf, cfp, n_src;
+    unsigned rows_per_cloud;    // M * K
+    bool vec;                   // cf % 4 == 0 and `points` 16-byte aligned
+};
+
+// four consecutive operand columns col .. col+3 (col a multiple of 4) of row `row`; zero outside
+__device__ __forceinline__ float4 load4_gathered(const GatherSrc &g, long long row, long long row_end, int col)
+{
+    const bool row_ok = row < row_end;
+    const long long r = row_ok ? row : 0;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < g.cfp) {
+        const unsigned cloud = static_cast<unsigned>(r) / g.rows_per_cloud;      // rows < 2^32 (checked by the launcher)
+        const float *p = g.points + (static_cast<size_t>(cloud) * g.n_src + g.idx[r]) * g.cf;
+        if (g.vec) {
+            const bool ok = row_ok && col < g.cf;
+            const float4 w = *reinterpret_cast<const float4 *>(p + (ok ? col : 0));
+            if (ok) v = w;
+        } else {
+            const bool k0 = row_ok && col < g.cf, k1 = row_ok && col + 1 < g.cf, k2 = row_ok && col + 2 < g.cf, k3 = row_ok && col + 3 < g.cf;
+            const float x = p[k0 ? col : 0], y = p[k1 ? col + 1 : 0], z = p[k2 ? col + 2 : 0], w = p[k3 ? col + 3 : 0];
+            v.x = k0 ? x : 0.f; v.y = k1 ? y : 0.f; v.z = k2 ? z : 0.f; v.w = k3 ? w : 0.f;
+        }
+    } else if (col == g.cfp) {
+        const float *q = g.gxyz + r * 3;
+        const float x = q[0], y = q[1], z = q[2];
+        if (row_ok) { v.x = x; v.y = y; v.z = z; }
+    }
+    return v;
+}
+
 // per-thread BN affine + ReLU of the four columns a thread stages: y = max(a (x - mu) + beta, 0) -- the difference first, as the
 // reference graph forms it: a x + (beta - mu a) loses |mu| / sigma digits around y = 0 and flips three times as many ReLU masks
 // against an fp64 evaluation (profiles/r03_grad_noise.md)
@@ -94,7 +134,7 @@ __device__ __forceinline__ float4 apply_col_act(const ColAct &f, float4 v, bool 
 // wgrad: partial[chunk][n][k] = sum over the chunk's rows of G[r][n] * act(X)[r][k]
 // WM / WN: 32x32 MFMA tiles per wave along Cout / Cin; a workgroup is 2 x 2 waves -> tile 64*WM x 64*WN.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, bool VEC>
+template <int WM, int WN, bool VEC, bool GATHER = false>
 __global__ __launch_bounds__(kGemmThreads) void wgrad_kernel(long long rows, int cout, int cin, int mtiles,
                                                              long long rows_per_chunk, const float *__restrict__ G,
                                                              const float *__restrict__ X,
@@ -102,7 +142,7 @@ __global__ __launch_bounds__(kGemmThreads) void wgrad_kernel(long long rows, int
                                                              const float *__restrict__ in_beta,
                                                              const float *__restrict__ in_mean,
                                                              const float *__restrict__ in_invstd,
-                                                             float *__restrict__ partial)
+                                                             float *__restrict__ partial, GatherSrc gs)
 {
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int GS = TM + 32, XS = TN + 32;  // LDS row strides: the two row-halves of a wave land on disjoint banks
@@ -135,7 +175,8 @@ __global__ __launch_bounds__(kGemmThreads) void wgrad_kernel(long long rows, int
 #pragma unroll
         for (int p = 0; p < GPASS; ++p) gr[p] = load4_guarded<VEC>(G, rt + grow + p * GROWS, r1, gcol, cout);
 #pragma unroll
-        for (int p = 0; p < XPASS; ++p) xr[p] = load4_guarded<VEC>(X, rt + xrow + p * XROWS, r1, xcol, cin);
+        for (int p = 0; p < XPASS; ++p)
+            xr[p] = GATHER ? load4_gathered(gs, rt + xrow + p * XROWS, r1, xcol) : load4_guarded<VEC>(X, rt + xrow + p * XROWS, r1, xcol, cin);
     };
     fetch(r0);
     for (long long rt = r0; rt < r1; rt += kGemmRowsPerStage) {
@@ -228,7 +269,7 @@ constexpr int kFwdKC = 32;      // input channels per LDS stage
 constexpr int kFwdLS = kFwdKC + 4;  // LDS row stride (keeps float4 stores aligned; 2-way read conflicts are noise here)
 constexpr int kFwdMaxCin = 1024;
 
-template <int NT, bool VEC>
+template <int NT, bool VEC, bool GATHER = false>
 __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2))) void linear_fwd_kernel(long long rows, int cin, int cout, long long ntiles,
                                                                   const float *__restrict__ X,
                                                                   const float *__restrict__ in_gamma,
@@ -237,7 +278,8 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                                                                   const float *__restrict__ in_invstd,
                                                                   const float *__restrict__ W,
                                                                   const float *__restrict__ bias, float *__restrict__ Z,
-                                                                  float *__restrict__ Hout, float *__restrict__ partial, int elu)
+                                                                  float *__restrict__ Hout, float *__restrict__ partial, int elu,
+                                                                  GatherSrc gs)
 {
     // elu: the layer order of PointCNN's dense (pointfly.py:480-497), linear -> ELU -> BatchNorm: the activation on load is
     // a (elu(x) - mu) + beta (no clamp) and the statistics in the epilogue are those of elu(z)
@@ -266,7 +308,8 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
     float4 ar[4], br[NT];
     auto fetch = [&](long long r0, int kc) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ar[p] = load4_guarded<VEC>(X, r0 + srow + 32 * p, rows, kc + k4, cin);
+        for (int p = 0; p < 4; ++p)
+            ar[p] = GATHER ? load4_gathered(gs, r0 + srow + 32 * p, rows, kc + k4) : load4_guarded<VEC>(X, r0 + srow + 32 * p, rows, kc + k4, cin);
 #pragma unroll
         for (int p = 0; p < NT; ++p) br[p] = load4_guarded<VEC>(W, srow + 32 * p, cout, kc + k4, cin);
     };
@@ -1008,11 +1051,27 @@ HF_API size_t hf_linear_wgrad_workspace(long long rows, int cout, int cin)
     return sizeof(float) * static_cast<size_t>(p.chunks) * cout * cin;
 }
 
-HF_API int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_z, const float *x, const float *in_gamma,
-                           const float *in_beta, const float *in_mean, const float *in_invstd, float *grad_weight,
-                           void *workspace, size_t workspace_bytes, hf_stream_t stream)
+static GatherSrc no_gather() { return GatherSrc{ nullptr, nullptr, nullptr, 0, 0, 0, 1u, false }; }
+
+// the A operand of a gathering launch; HF_EINVAL when the arguments do not describe one
+static int make_gather(long long rows, int c_feat, const float *points, int n_src, long long rows_per_cloud, const int *idx,
+                       const float *gxyz, GatherSrc *g)
 {
-    if (rows <= 0 || cout <= 0 || cin <= 0 || cout > 4096 || cin > 4096 || !grad_z || !x || !grad_weight) return HF_EINVAL;
+    if (rows <= 0 || rows > 0x7fffffffll || c_feat < 0 || c_feat > kFwdMaxCin - 4 || n_src <= 0 || rows_per_cloud <= 0 ||
+        rows_per_cloud > rows || rows % rows_per_cloud != 0 || !idx || !gxyz || (c_feat > 0 && !points))
+        return HF_EINVAL;
+    g->points = points; g->idx = idx; g->gxyz = gxyz;
+    g->cf = c_feat; g->cfp = (c_feat + 3) & ~3; g->n_src = n_src;
+    g->rows_per_cloud = static_cast<unsigned>(rows_per_cloud);
+    g->vec = c_feat > 0 && c_feat % 4 == 0 && reinterpret_cast<uintptr_t>(points) % 16 == 0;
+    return HF_OK;
+}
+
+static int linear_wgrad_impl(long long rows, int cout, int cin, const float *grad_z, const float *x, const float *in_gamma,
+                             const float *in_beta, const float *in_mean, const float *in_invstd, float *grad_weight,
+                             void *workspace, size_t workspace_bytes, hf_stream_t stream, const GatherSrc *gather)
+{
+    if (rows <= 0 || cout <= 0 || cin <= 0 || cout > 4096 || cin > 4096 || !grad_z || (!x && !gather) || !grad_weight) return HF_EINVAL;
     if (in_gamma && (!in_beta || !in_mean || !in_invstd)) return HF_EINVAL;
     if (!workspace || workspace_bytes < hf_linear_wgrad_workspace(rows, cout, cin)) return HF_EWORKSPACE;
     const WgradPlan p = wgrad_plan(rows, cout, cin);
@@ -1020,13 +1079,15 @@ HF_API int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     const dim3 grid(p.mtiles * p.ntiles, p.chunks);
-    const bool vec = vec4_ok(grad_z, cout) && vec4_ok(x, cin);
-#define HF_WGRAD(M, N, V)                                                                                               \
-    hipLaunchKernelGGL((wgrad_kernel<M, N, V>), grid, dim3(kGemmThreads), 0, st, rows, cout, cin, p.mtiles,              \
-                       p.rows_per_chunk, grad_z, x, in_gamma, in_beta, in_mean, in_invstd, partial)
+    const bool vec = vec4_ok(grad_z, cout) && (gather || vec4_ok(x, cin));
+    const GatherSrc gs = gather ? *gather : no_gather();
+#define HF_WGRAD(M, N, V, GA)                                                                                           \
+    hipLaunchKernelGGL((wgrad_kernel<M, N, V, GA>), grid, dim3(kGemmThreads), 0, st, rows, cout, cin, p.mtiles,          \
+                       p.rows_per_chunk, grad_z, x, in_gamma, in_beta, in_mean, in_invstd, partial, gs)
 #define HF_WGRAD_V(M, N)                                                                                                \
     do {                                                                                                                \
-        if (vec) HF_WGRAD(M, N, true); else HF_WGRAD(M, N, false);                                                      \
+        if (gather) { if (vec) HF_WGRAD(M, N, true, true); else HF_WGRAD(M, N, false, true); }                          \
+        else if (vec) HF_WGRAD(M, N, true, false); else HF_WGRAD(M, N, false, false);                                   \
     } while (0)
     if (p.wm == 2 && p.wn == 2) HF_WGRAD_V(2, 2);
     else if (p.wm == 2) HF_WGRAD_V(2, 1);
@@ -1040,6 +1101,24 @@ HF_API int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_
     return launch_status();
 }
 
+HF_API int hf_linear_wgrad(long long rows, int cout, int cin, const float *grad_z, const float *x, const float *in_gamma,
+                           const float *in_beta, const float *in_mean, const float *in_invstd, float *grad_weight,
+                           void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    return linear_wgrad_impl(rows, cout, cin, grad_z, x, in_gamma, in_beta, in_mean, in_invstd, grad_weight, workspace, workspace_bytes,
+                             stream, nullptr);
+}
+
+HF_API int hf_linear_wgrad_gather(long long rows, int cout, int c_feat, const float *grad_z, const float *points, int n_src,
+                                  long long rows_per_cloud, const int *idx, const float *grouped_xyz, float *grad_weight,
+                                  void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    GatherSrc g;
+    if (const int rc = make_gather(rows, c_feat, points, n_src, rows_per_cloud, idx, grouped_xyz, &g); rc != HF_OK) return rc;
+    return linear_wgrad_impl(rows, cout, g.cfp + 4, grad_z, nullptr, nullptr, nullptr, nullptr, nullptr, grad_weight, workspace,
+                             workspace_bytes, stream, &g);
+}
+
 HF_API size_t hf_linear_bn_fwd_workspace(int cout)
 {
     return cout > 0 ? sizeof(float) * 2 * static_cast<size_t>(cout) * kBnMaxBlocks : 0;
@@ -1048,9 +1127,9 @@ HF_API size_t hf_linear_bn_fwd_workspace(int cout)
 static int linear_bn_fwd_impl(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,
                               const float *in_mean, const float *in_invstd, float *x_act, const float *weight,
                               const float *bias, float *z, float eps, float momentum, float *running_mean, float *running_var, float *mean, float *invstd,
-                              void *workspace, size_t workspace_bytes, hf_stream_t stream, int elu)
+                              void *workspace, size_t workspace_bytes, hf_stream_t stream, int elu, const GatherSrc *gather = nullptr)
 {
-    if (rows <= 0 || cin <= 0 || cout <= 0 || cin > kFwdMaxCin || cout > 256 || !x || !weight || !z || !mean || !invstd)
+    if (rows <= 0 || cin <= 0 || cout <= 0 || cin > kFwdMaxCin || cout > 256 || (!x && !gather) || !weight || !z || !mean || !invstd)
         return HF_EINVAL;
     if (in_gamma && (!in_beta || !in_mean || !in_invstd)) return HF_EINVAL;
     if (x_act && !in_gamma) return HF_EINVAL;
@@ -1058,15 +1137,17 @@ static int linear_bn_fwd_impl(long long rows, int cin, int cout, const float *x,
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     const long long ntiles = (rows + kFwdRows - 1) / kFwdRows;
-    const bool vec = vec4_ok(x, cin) && vec4_ok(weight, cin) && (!x_act || vec4_ok(x_act, cin));
+    const bool vec = (gather || vec4_ok(x, cin)) && vec4_ok(weight, cin) && (!x_act || vec4_ok(x_act, cin));
     const int nt = div_up(cout, 32);
     const int nblk = resident_grid(nt, ntiles);
-#define HF_FWD(N, V)                                                                                                    \
-    hipLaunchKernelGGL((linear_fwd_kernel<N, V>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, cin, cout, ntiles, x,    \
-                       in_gamma, in_beta, in_mean, in_invstd, weight, bias, z, x_act, partial, elu)
+    const GatherSrc gs = gather ? *gather : no_gather();
+#define HF_FWD(N, V, GA)                                                                                                \
+    hipLaunchKernelGGL((linear_fwd_kernel<N, V, GA>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, cin, cout, ntiles, x, \
+                       in_gamma, in_beta, in_mean, in_invstd, weight, bias, z, x_act, partial, elu, gs)
 #define HF_FWD_V(N)                                                                                                     \
     case N:                                                                                                             \
-        if (vec) HF_FWD(N, true); else HF_FWD(N, false);                                                                \
+        if (gather) { if (vec) HF_FWD(N, true, true); else HF_FWD(N, false, true); }                                    \
+        else if (vec) HF_FWD(N, true, false); else HF_FWD(N, false, false);                                             \
         break
     switch (nt) {
         HF_FWD_V(1); HF_FWD_V(2); HF_FWD_V(3); HF_FWD_V(4); HF_FWD_V(5); HF_FWD_V(6); HF_FWD_V(7); HF_FWD_V(8);
@@ -1085,6 +1166,17 @@ HF_API int hf_linear_bn_fwd(long long rows, int cin, int cout, const float *x, c
 {
     return linear_bn_fwd_impl(rows, cin, cout, x, in_gamma, in_beta, in_mean, in_invstd, x_act, weight, bias, z, eps, momentum, running_mean,
                               running_var, mean, invstd, workspace, workspace_bytes, stream, 0);
+}
+
+HF_API int hf_linear_bn_fwd_gather(long long rows, int c_feat, int cout, const float *points, int n_src, long long rows_per_cloud,
+                                   const int *idx, const float *grouped_xyz, const float *weight, const float *bias, float *z, float eps,
+                                   float momentum, float *running_mean, float *running_var, float *mean, float *invstd, void *workspace,
+                                   size_t workspace_bytes, hf_stream_t stream)
+{
+    GatherSrc g;
+    if (const int rc = make_gather(rows, c_feat, points, n_src, rows_per_cloud, idx, grouped_xyz, &g); rc != HF_OK) return rc;
+    return linear_bn_fwd_impl(rows, g.cfp + 4, cout, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, weight, bias, z, eps, momentum,
+                              running_mean, running_var, mean, invstd, workspace, workspace_bytes, stream, 0, &g);
 }
 
 HF_API int hf_linear_elu_bn_fwd(long long rows, int cin, int cout, const float *x, const float *in_gamma, const float *in_beta,

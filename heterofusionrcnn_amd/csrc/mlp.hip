@@ -81,83 +81,10 @@ __device__ __forceinline__ void reduce_rows(float (&a)[VEC], float (&b)[VEC], in
 // normalisation and the backward pass then see elu(x), computed on load -- the activation never exists in memory.
 constexpr int kBnRelu = 1, kBnEluIn = 2;
 
-// ---- the finalize step folded into its producer (round 4) ----
-// Each BatchNorm pass used to be followed by a one-workgroup-per-channel kernel that sums the per-block partials in fp64:
-// 158 launches per train step, 4.7 us each at one frame per GPU.  For small layers (c * nblk <= kBnFoldMax partial pairs) the
-// producing kernel does it itself: every workgroup takes a ticket after its partials are written (agent-scope release
-// before, acquire after: the per-XCD L2s are not coherent with each other), and the workgroup that draws the LAST ticket
-// reduces all channels -- 32 lanes per channel, fixed summation order (deterministic), fp64 -- writes the results and puts
-// the ticket counter back to zero.  The counters live in the code object; a launch gets the next of kBnTickets in turn
-// (captured graphs keep theirs), so two launches share one only if kBnTickets other BatchNorm passes lie between them.
-constexpr int kBnTickets = 4096;
-constexpr long long kBnFoldMax = 32768;
-__device__ unsigned g_bn_tickets[kBnTickets];
-
-struct BnFold {
-    int ticket;                 // < 0: no fold (a finalize kernel follows)
-    int bwd;                    // 0: batch statistics (+ running statistics); 1: dbeta / dgamma
-    long long rows;
-    float eps, momentum;
-    float *running_mean, *running_var;
-    float *out0, *out1;         // save_mean, save_invstd | dbeta, dgamma
-};
-
-static int bn_next_ticket()
-{
-    static unsigned next = 0;   // launches are enqueued by one host thread at a time per library instance in practice; a race
-    return static_cast<int>(__atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % kBnTickets);   // here would only repeat an index
-}
-
-static BnFold bn_no_fold() { return BnFold{ -1, 0, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr }; }
-static bool bn_folds(int c, int nblk) { return static_cast<long long>(c) * nblk <= kBnFoldMax && nblk > 0; }
-
-// called by ALL threads of every workgroup of the producing kernel, after the partials are stored
-__device__ __forceinline__ void bn_fold_finalize(const BnFold &f, int c, int nblk, const float *partial)
-{
-    if (f.ticket < 0) return;   // uniform
-    __shared__ int last_flag;
-    const int t = threadIdx.x;
-    __threadfence();            // release (agent scope): this wave's partials leave its XCD's L2
-    __syncthreads();
-    if (t == 0) last_flag = atomicAdd(&g_bn_tickets[f.ticket], 1u) == gridDim.x - 1u ? 1 : 0;
-    __syncthreads();
-    if (!last_flag) return;     // uniform
-    __threadfence();            // acquire: the other workgroups' partials, whatever XCD wrote them
-    const int ngrp = static_cast<int>(blockDim.x) >> 5, grp = t >> 5, lane32 = t & 31;
-    if (grp < ngrp) {
-        for (int ch = grp; ch < c; ch += ngrp) {
-            const float *p0 = partial + static_cast<size_t>(ch) * kBnMaxBlocks;
-            const float *p1 = partial + static_cast<size_t>(c + ch) * kBnMaxBlocks;
-            double a = 0.0, b = 0.0;
-            for (int i = lane32; i < nblk; i += 32) {
-                a += static_cast<double>(__builtin_nontemporal_load(p0 + i));
-                b += static_cast<double>(__builtin_nontemporal_load(p1 + i));
-            }
-#pragma unroll
-            for (int w = 16; w > 0; w >>= 1) { a += __shfl_xor(a, w); b += __shfl_xor(b, w); }
-            if (lane32 == 0) {
-                if (f.bwd) {
-                    f.out0[ch] = static_cast<float>(a);
-                    f.out1[ch] = static_cast<float>(b);
-                } else {
-                    const double mean = a / static_cast<double>(f.rows);
-                    double var = b / static_cast<double>(f.rows) - mean * mean;
-                    if (var < 0.0) var = 0.0;
-                    f.out0[ch] = static_cast<float>(mean);
-                    f.out1[ch] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(f.eps)));
-                    if (f.running_mean) f.running_mean[ch] = (1.0f - f.momentum) * f.running_mean[ch] + f.momentum * static_cast<float>(mean);
-                    if (f.running_var) f.running_var[ch] = (1.0f - f.momentum) * f.running_var[ch] + f.momentum * static_cast<float>(var);
-                }
-            }
-        }
-    }
-    if (t == 0) g_bn_tickets[f.ticket] = 0u;   // ready for the launch that draws this index next
-}
-
 // partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over the block's rows
 template <int VEC>
 __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
-                                const float *__restrict__ x, float *__restrict__ partial, int elu_in, BnFold fold)
+                                const float *__restrict__ x, float *__restrict__ partial, int elu_in)
 {
     extern __shared__ float smem[];
     const int t = threadIdx.x;
@@ -181,7 +108,6 @@ __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long lon
             partial[(static_cast<size_t>(c + cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = q[i];
         }
     }
-    bn_fold_finalize(fold, c, static_cast<int>(gridDim.x), partial);
 }
 
 // one 256-thread workgroup per channel: fp64 tree reduction of that channel's two partial rows
@@ -268,7 +194,7 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
                                      const float *__restrict__ x, const float *__restrict__ dy,
                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                      const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                                     float *__restrict__ partial, long long lddy, BnFold fold)
+                                     float *__restrict__ partial, long long lddy)
 {
     extern __shared__ float smem[];
     const int t = threadIdx.x;
@@ -305,7 +231,6 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
             partial[(static_cast<size_t>(c + cvec * VEC + i)) * kBnMaxBlocks + blockIdx.x] = s2[i];
         }
     }
-    bn_fold_finalize(fold, c, static_cast<int>(gridDim.x), partial);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int c, int nblk, const float *__restrict__ partial,
@@ -542,26 +467,6 @@ void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma
 
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
-// statistics pass (+ its finalize: folded into the pass for small layers, else the per-channel kernel)
-static void launch_bn_stats_pass(const BnGeom &g, long long rows, int c, const float *x, float *partial, int elu_in, float eps,
-                                 float momentum, float *running_mean, float *running_var, float *save_mean, float *save_invstd,
-                                 hipStream_t st)
-{
-    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-    const bool fold = bn_folds(c, g.nblk);
-    const BnFold f = fold ? BnFold{ bn_next_ticket(), 0, rows, eps, momentum, running_mean, running_var, save_mean, save_invstd }
-                          : bn_no_fold();
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial, elu_in, f);
-    else
-        hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial, elu_in, f);
-    if (!fold)
-        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps, momentum,
-                           running_mean, running_var, save_mean, save_invstd);
-}
-
 }  // namespace hf
 
 using namespace hf;
@@ -586,8 +491,15 @@ HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const 
     if (g.vec == 4 && !(aligned16(x) && aligned16(y) && ld_ok4(ldy))) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
-    launch_bn_stats_pass(g, rows, c, x, partial, (relu & kBnEluIn) ? 1 : 0, eps, momentum, running_mean, running_var, save_mean,
-                         save_invstd, st);
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, partial, (relu & kBnEluIn) ? 1 : 0);
+    else
+        hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, partial, (relu & kBnEluIn) ? 1 : 0);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps,
+                       momentum, running_mean, running_var, save_mean, save_invstd);
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
                            g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
@@ -616,7 +528,14 @@ HF_API int hf_bn_stats(long long rows, int c, const float *x, float eps, float m
     if (g.vec == 4 && !aligned16(x)) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
-    launch_bn_stats_pass(g, rows, c, x, partial, 0, eps, momentum, running_mean, running_var, save_mean, save_invstd, st);
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+    if (g.vec == 4)
+        hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, partial, 0);
+    else
+        hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                           g.rows_per_block, x, partial, 0);
+    launch_bn_stats_finalize(rows, c, g.nblk, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd, st);
     return launch_status();
 }
 
@@ -650,15 +569,13 @@ HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float 
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-    const bool fold = bn_folds(c, g.nblk);
-    const BnFold f = fold ? BnFold{ bn_next_ticket(), 1, rows, 0.f, 0.f, nullptr, nullptr, dbeta, dgamma } : bn_no_fold();
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy, f);
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy, f);
-    if (!fold) hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, partial, dgamma, dbeta);
+                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, partial, dgamma, dbeta);
     float *cpart = dx_colsum ? partial : nullptr;  // the reduce partials were consumed by the finalize kernel above
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
@@ -716,7 +633,15 @@ HF_API int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z
         BnGeom g = bn_geom(rows, c);
         if (g.vec == 4 && !aligned16(z)) return HF_EINVAL;
         float *partial = static_cast<float *>(workspace);
-        launch_bn_stats_pass(g, rows, c, z, partial, 0, eps, momentum, running_mean, running_var, mean, invstd, st);
+        const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+        if (g.vec == 4)
+            hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                               g.rows_per_block, z, partial, 0);
+        else
+            hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
+                               g.rows_per_block, z, partial, 0);
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps, momentum,
+                           running_mean, running_var, mean, invstd);
     }
     BnGeom gg = bn_geom(groups, c);
     if (gg.vec == 4 && !aligned16(z)) return HF_EINVAL;

@@ -16,6 +16,12 @@ frame per GPU (BASELINE config 4: a batch of 8 over 8 GPUs).  Here the step is c
   random numbers   dropout and the path-drop coin flips draw from the device generator, whose Philox offset PyTorch
                    advances per replay: every step sees fresh masks, as in eager mode (tests/test_graph_step.py).
 
+  two graphs       with several ranks and a model whose backward pass can be cut (the PointCNN RPN: everything after the encoder
+                   | the encoder), the step is captured as TWO graphs: the first ends when the gradients of the late half of
+                   the parameters (decoder, fc, heads: produced first) sit in their chunk of the flat buffer, whose all-reduce
+                   then runs on the collective's stream WHILE the second graph replays the encoder's backward pass; the second
+                   chunk follows.  One exchange of 54 MB after the graph was ~10 % of a 9 ms step at one frame per GPU.
+
 No work is skipped or cached: a replay launches exactly the kernels the eager step launches.
 """
 import torch
@@ -73,20 +79,27 @@ class FlatGrads:
         self.flat.zero_()
 
     def gather(self, grads):
-        """grads: one tensor (or None = zero gradient) per parameter"""
-        dst = [v for v, g in zip(self.views, grads) if g is not None]
-        src = [g for g in grads if g is not None]
+        """grads: one tensor (or None = zero gradient, False = leave the slot alone) per parameter"""
+        dst = [v for v, g in zip(self.views, grads) if g is not None and g is not False]
+        src = [g for g in grads if g is not None and g is not False]
         for v, g in zip(self.views, grads):
-            if g is None:
+            if g is None:                                              # False: not this call's business (the other chunk)
                 v.zero_()
         if dst:
             torch._foreach_copy_(dst, src)
 
-    def all_reduce_mean(self, world):
-        """hvd.DistributedOptimizer: the average over the replicas, one collective for the whole model"""
+    def all_reduce_mean(self, world, scale=True):
+        """hvd.DistributedOptimizer: the average over the replicas, one collective for the whole model (scale=False: the sum;
+        the optimizer then applies 1 / world itself while it loads the gradients)"""
         if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.mul_(1.0 / world)
+            if scale:
+                self.flat.mul_(1.0 / world)
+
+    def segment(self, first, count):
+        """the contiguous slice of the flat buffer that holds parameters first .. first + count - 1"""
+        o0 = sum(p.numel() for p in self.params[:first])
+        return self.flat[o0:o0 + sum(p.numel() for p in self.params[first:first + count])]
 
 
 def broadcast_parameters(module, src=0):
@@ -110,11 +123,23 @@ class TrainStep:
     initialisations, optimizer state); their effect on parameters, buffers and optimizer state is undone before the capture, so
     the first replay starts from the state the caller handed in -- the same trajectory as graph=False."""
 
-    def __init__(self, model, optimizer, inputs, geometry, world=1, graph=True, loss_fn=None, warmup=3):
+    def __init__(self, model, optimizer, inputs, geometry, world=1, graph=True, loss_fn=None, warmup=3, overlap_exchange=True):
         self.model, self.opt, self.world = model, optimizer, world
         self.loss_fn = loss_fn or _rpn_loss
-        self.grads = FlatGrads(model.parameters())
         self.flat_mode = world > 1                 # one rank: the optimizer reads the gradients where autograd leaves them
+        # the cut of the backward pass: parameters of the encoder ("early": their gradients come last) | everything else
+        enc = getattr(getattr(model, "backbone", None), "enc", None)
+        self.split = bool(overlap_exchange and self.flat_mode and loss_fn is None and enc is not None)
+        early_ids = {id(p) for p in enc.parameters()} if self.split else set()
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.late = [p for p in params if id(p) not in early_ids]
+        self.early = [p for p in params if id(p) in early_ids]
+        self.grads = FlatGrads(self.late + self.early)        # [late | early]: each chunk one contiguous slice
+        self.chunks = 2 if self.split else 1
+        # optim.MultiTensorAdam multiplies the gradients by 1 / world on load: the flat buffer then carries the SUM
+        self.opt_scales = self.flat_mode and hasattr(optimizer, "grad_scale")
+        if self.opt_scales:
+            optimizer.grad_scale = 1.0 / world
         self.inputs = dict(inputs)
         self.geometry = tree_map(geometry, lambda t: t.clone())       # static slots
         self._geo_slots = tree_tensors(self.geometry)
@@ -140,9 +165,45 @@ class TrainStep:
 
     def _finish(self):
         if self.flat_mode:
-            self.grads.all_reduce_mean(self.world)
+            self.grads.all_reduce_mean(self.world, scale=not self.opt_scales)
             self.grads.adopt()                                        # the optimizer steps on the averaged views
         self.opt.step()
+
+    # ---- the step cut in two (several ranks): [forward, loss, backward down to the encoder's outputs] | [the encoder's backward]
+    def _first_half(self):
+        self.grads.release()
+        img = self.inputs.get("img_fts")
+        img_leaf = img is not None and img.requires_grad
+        if img_leaf:
+            img.grad = None
+        taps = []
+        loss = _rpn_loss(self.model, self.inputs, self.geometry, taps=taps)
+        # taps = (encoder output, detached copy read by everything downstream): the copies are leaves, so their gradients hold
+        # the downstream paths only and the encoder's graph is untouched by this call
+        wanted = self.late + [c for _, c in taps] + ([img] if img_leaf else [])
+        got = torch.autograd.grad(loss, wanted, allow_unused=True)
+        n = len(self.late)
+        self._taps, self._tap_grads = [t for t, _ in taps], list(got[n:n + len(taps)])
+        if img_leaf:
+            img.grad = got[-1]
+        self.grads.gather(list(got[:n]) + [False] * len(self.early))
+        return loss.detach()
+
+    def _second_half(self):
+        live = [(t, g) for t, g in zip(self._taps, self._tap_grads) if g is not None]
+        got = torch.autograd.grad([t for t, _ in live], self.early, grad_outputs=[g for _, g in live], allow_unused=True)
+        self.grads.gather([False] * len(self.late) + list(got))
+
+    def _exchange_overlapped(self, second):
+        """chunk 0 (late parameters) is reduced while `second` (the encoder's backward pass) runs; then chunk 1"""
+        n = len(self.late)
+        c0, c1 = self.grads.segment(0, n), self.grads.segment(n, len(self.early))
+        work = dist.all_reduce(c0, op=dist.ReduceOp.SUM, async_op=True)    # on the collective's stream, after what is enqueued here
+        second()
+        dist.all_reduce(c1, op=dist.ReduceOp.SUM)
+        work.wait()                                                         # this stream waits for chunk 0 as well
+        if not self.opt_scales:
+            self.grads.flat.mul_(1.0 / self.world)
 
     def _capture(self, warmup):
         # PyTorch's recipe: a few eager iterations on a side stream (lazy initialisations, allocator warm-up, optimizer
@@ -162,10 +223,18 @@ class TrainStep:
         self._restore(snap)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._forward_backward()
-            if self.opt_in_graph:
-                self.opt.step()
+        if self.split:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._first_half()
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                self._second_half()
+            self._taps = self._tap_grads = None                       # the graphs own what they need; drop the autograd graph
+        else:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._forward_backward()
+                if self.opt_in_graph:
+                    self.opt.step()
         # the captured backward writes its gradients into the graph's own pool at every replay, whatever .grad points to
         # afterwards: with several ranks the parameters adopt the flat views (filled by the captured foreach copy)
         if self.flat_mode:
@@ -174,8 +243,11 @@ class TrainStep:
     def _snapshot(self):
         with torch.no_grad():
             tensors = [t for t in list(self.model.parameters()) + list(self.model.buffers())]
-            state = {id(t): {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
-                     for t, st in self.opt.state.items()}
+            if hasattr(self.opt, "snapshot"):                           # optim.MultiTensorAdam: two flat moment buffers + the counter
+                state = self.opt.snapshot()
+            else:
+                state = {id(t): {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                         for t, st in self.opt.state.items()}
             return [(t, t.clone()) for t in tensors], state
 
     def _restore(self, snap):
@@ -183,6 +255,9 @@ class TrainStep:
         with torch.no_grad():
             if tensors:
                 torch._foreach_copy_([t for t, _ in tensors], [c for _, c in tensors])
+            if hasattr(self.opt, "restore"):
+                self.opt.restore(state)
+                return
             for t, st in self.opt.state.items():                       # state the warm-up created: back to its initial zeros
                 old = state.get(id(t), {})
                 for k, v in st.items():
@@ -209,19 +284,28 @@ class TrainStep:
 
     def __call__(self, geometry=None, **inputs):
         self.load(geometry, **inputs)
-        if self.graph is None:
+        if self.graph is None and self.split:
+            self.loss = self._first_half()
+            self._exchange_overlapped(self._second_half)
+            self.grads.adopt()
+            self.opt.step()
+        elif self.graph is None:
             self.loss = self._forward_backward()
             self._finish()
+        elif self.split:
+            self.graph.replay()
+            self._exchange_overlapped(self.graph2.replay)
+            self.opt.step()
         else:
             self.graph.replay()
             if not self.opt_in_graph:
-                self.grads.all_reduce_mean(self.world)
+                self.grads.all_reduce_mean(self.world, scale=not self.opt_scales)
                 self.opt.step()
         return self.loss
 
 
-def _rpn_loss(model, inputs, geometry):
+def _rpn_loss(model, inputs, geometry, taps=None):
     seg_logits, head = model(inputs["xyz"], inputs["intensity"], geometry=geometry, img_fts=inputs.get("img_fts"),
-                             calib=inputs.get("calib"))
+                             calib=inputs.get("calib"), **({"taps": taps} if taps is not None else {}))
     loss, _ = model.loss(inputs["xyz"], seg_logits, head, inputs["label_cls"], inputs["label_reg"])
     return loss

@@ -254,13 +254,17 @@ class _SharedMLPChain(torch.autograd.Function):
     Backward: per layer the fused BN backward (dz, dgamma, dbeta), split-K dW, dX = dz W."""
 
     @staticmethod
-    def forward(ctx, x, pool_k, layers, *params):
+    def forward(ctx, x, pool_k, layers, first, *params):
+        """first = (mean0, invstd0): x IS the first layer's pre-BN output (its linear ran in _GatherLinear, on neighbourhoods
+        read in place); the node then starts at that layer's BatchNorm and hands dz0 back as the gradient of x"""
         L = _lib.lib()
         n = len(layers)
         saved, cur, in_bn = [], x, None
         for li, layer in enumerate(layers):
             w, b, gamma, beta = params[4 * li:4 * li + 4]
-            if _mfma_forward_pays(cur.shape[0], w.shape[1], w.shape[0]):
+            if li == 0 and first is not None:
+                xin, z, mean, invstd = x.new_empty(0), x, first[0], first[1]
+            elif _mfma_forward_pays(cur.shape[0], w.shape[1], w.shape[0]):
                 z, mean, invstd, x_act = linear_bn_fwd(cur, w, b, layer.bn, in_bn, keep_act=True)
                 xin = x_act if x_act is not None else cur
             else:  # library GEMM on the materialised input, statistics in their own pass
@@ -285,7 +289,7 @@ class _SharedMLPChain(torch.autograd.Function):
         for t in saved:
             flat.extend(t)
         ctx.save_for_backward(*flat, *params, *([argmax] if argmax is not None else []))
-        ctx.n, ctx.pool_k = n, pool_k
+        ctx.n, ctx.pool_k, ctx.first = n, pool_k, first is not None
         return out
 
     @staticmethod
@@ -310,7 +314,8 @@ class _SharedMLPChain(torch.autograd.Function):
             w, b, gamma, beta = params[4 * li:4 * li + 4]
             rows, cout = z.shape
             cin = w.shape[1]
-            need_dx = li > 0 or ctx.needs_input_grad[0]
+            gathered = li == 0 and ctx.first                       # this layer's linear lives in _GatherLinear: stop at dz
+            need_dx = (li > 0 or ctx.needs_input_grad[0]) and not gathered
             mfma = need_dx and _mfma_backward_pays(rows, cin, cout)
             dbias = zero_bias[sum(couts[:li]):sum(couts[:li + 1])]
             dz, from_dy = None, False
@@ -358,18 +363,25 @@ class _SharedMLPChain(torch.autograd.Function):
                 dy = dx
             elif need_dx:
                 dy = dz @ w
-            grads[4 * li:4 * li + 4] = [_splitk_wgrad(dz, xin), dbias, dgamma, dbeta]
-        return (dy if ctx.needs_input_grad[0] else None, None, None, *grads)
+            if gathered:
+                dy = dz
+                grads[0:4] = [None, None, dgamma, dbeta]
+            else:
+                grads[4 * li:4 * li + 4] = [_splitk_wgrad(dz, xin), dbias, dgamma, dbeta]
+        return (dy if ctx.needs_input_grad[0] else None, None, None, None, *grads)
 
 
-def _shared_mlp_eval(layers, x, pool_k, extra):
-    """inference twin of _SharedMLPChain.forward: running statistics instead of batch statistics, nothing saved"""
+def _shared_mlp_eval(layers, x, pool_k, extra, first_done=False):
+    """inference twin of _SharedMLPChain.forward: running statistics instead of batch statistics, nothing saved.
+    first_done: x is already the first layer's pre-BN output (shared_mlp_grouped)"""
     L = _lib.lib()
     cur, in_bn = x, None
     for i, layer in enumerate(layers):
         w = layer.fc.weight if (i or not extra) else torch.nn.functional.pad(layer.fc.weight, (0, extra))
         bn = layer.bn
-        if _mfma_forward_pays(cur.shape[0], w.shape[1], w.shape[0]):
+        if i == 0 and first_done:
+            z = x
+        elif _mfma_forward_pays(cur.shape[0], w.shape[1], w.shape[0]):
             z = linear_bn_fwd(cur, w, layer.fc.bias, bn, in_bn, update_running=False)[0]
         else:
             xin = _bn_apply(cur, *in_bn) if in_bn is not None else cur
@@ -383,6 +395,117 @@ def _shared_mlp_eval(layers, x, pool_k, extra):
     check(L.hf_bn_relu_maxpool_fwd(rows // pool_k, pool_k, cout, ptr(cur), ptr(gamma), ptr(beta), 0, 0.0, 0.0, None, None,
                                    ptr(mean), ptr(invstd), ptr(out), None, None, 0, stream_ptr()), "bn_relu_maxpool_fwd")
     return out
+
+
+def _gather_weight(w, c, xyz_first):
+    """the first layer's weight (cout, 3 + c) in the reference's column order ([xyz | features], pointnet_util.py:58-60, or
+    [features | xyz] in the multi-scale module, :264) -> the gathering kernels' order [features, 0.., x, y, z, 0]"""
+    cfp = (c + 3) // 4 * 4
+    wx, wf = (w[:, :3], w[:, 3:3 + c]) if xyz_first else (w[:, c:c + 3], w[:, :c])
+    out = w.new_zeros((w.shape[0], cfp + 4))
+    out[:, :c] = wf
+    out[:, cfp:cfp + 3] = wx
+    return out
+
+
+def _ungather_weight(dw_int, c, xyz_first):
+    cfp = (c + 3) // 4 * 4
+    parts = [dw_int[:, cfp:cfp + 3], dw_int[:, :c]]
+    return torch.cat(parts if xyz_first else parts[::-1], dim=1)
+
+
+class _GatherLinear(torch.autograd.Function):
+    """z0 = [points[idx] | grouped_xyz] W^T + b with the batch statistics of z0, the neighbourhoods read IN PLACE
+    (hf_linear_bn_fwd_gather / hf_linear_wgrad_gather): the (B,M,K,C+3) tensor of sample_and_group is never written,
+    neither for the forward GEMM nor for the weight gradient.  Returns (z0, mean, invstd); the BatchNorm that consumes them
+    is the head of _SharedMLPChain (first=...)."""
+
+    @staticmethod
+    def forward(ctx, points, idx, gxyz, weight, bias, bn, xyz_first, update_running):
+        L = _lib.lib()
+        b, m, k = idx.shape
+        rows = b * m * k
+        c = points.shape[2] if points is not None else 0
+        n_src = points.shape[1] if points is not None else 1
+        cout = weight.shape[0]
+        dev = idx.device
+        wi = _gather_weight(weight, c, xyz_first)
+        z = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        mean = torch.empty((cout,), dtype=torch.float32, device=dev)
+        invstd = torch.empty((cout,), dtype=torch.float32, device=dev)
+        nbytes = L.hf_linear_bn_fwd_workspace(cout)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+        if update_running:
+            running_stats_written()
+        check(L.hf_linear_bn_fwd_gather(rows, c, cout, ptr(points), n_src, m * k, ptr(idx), ptr(gxyz), ptr(wi), ptr(bias), ptr(z),
+                                        bn.eps, bn.momentum, ptr(bn.running_mean) if update_running else None,
+                                        ptr(bn.running_var) if update_running else None, ptr(mean), ptr(invstd), ptr(ws), nbytes,
+                                        stream_ptr()), "linear_bn_fwd_gather")
+        ctx.save_for_backward(idx, gxyz, weight, *([points] if points is not None else []))
+        ctx.dims = (b, m, k, c, n_src, cout, xyz_first)
+        ctx.mark_non_differentiable(mean, invstd)
+        return z, mean, invstd
+
+    @staticmethod
+    def backward(ctx, dz, _dmean, _dinvstd):
+        L = _lib.lib()
+        idx, gxyz, weight, *rest = ctx.saved_tensors
+        points = rest[0] if rest else None
+        b, m, k, c, n_src, cout, xyz_first = ctx.dims
+        rows = b * m * k
+        dz = dz.contiguous()
+        cin = (c + 3) // 4 * 4 + 4
+        nbytes = L.hf_linear_wgrad_workspace(rows, cout, cin)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=dz.device)
+        dwi = torch.empty((cout, cin), dtype=torch.float32, device=dz.device)
+        check(L.hf_linear_wgrad_gather(rows, cout, c, ptr(dz), ptr(points), n_src, m * k, ptr(idx), ptr(gxyz), ptr(dwi), ptr(ws),
+                                       nbytes, stream_ptr()), "linear_wgrad_gather")
+        dw = _ungather_weight(dwi, c, xyz_first)
+        dpoints = None
+        if points is not None and ctx.needs_input_grad[0]:
+            wf = (weight[:, 3:3 + c] if xyz_first else weight[:, :c]).contiguous()
+            dg = dz @ wf                                               # (rows, c): the gradient of the gathered features
+            dpoints = torch.empty((b, n_src, c), dtype=torch.float32, device=dz.device)
+            check(L.hf_group_point_grad(b, n_src, c, m, k, ptr(dg), ptr(idx), ptr(dpoints), stream_ptr()), "group_point_grad")
+        # the bias feeds a BatchNorm: its gradient is exactly zero (see _SharedMLPChain.backward)
+        return dpoints, None, None, dw, torch.zeros((cout,), dtype=torch.float32, device=dz.device), None, None, None
+
+
+GATHER_MAX_COUT = 256           # accumulator tiles of the MFMA forward kernel
+GATHER_MAX_CFEAT = 1020
+
+
+def grouped_mlp_fusable(layers, points, idx):
+    """shared_mlp_grouped's conditions: BatchNorm + ReLU on every layer, on the device, first layer within the MFMA kernel's
+    range (Cout <= 256), pool_k <= 255"""
+    first = layers[0]
+    c = points.shape[2] if points is not None else 0
+    return (idx.is_cuda and all(l.bn is not None and l.bn.relu for l in layers) and first.fc.out_features <= GATHER_MAX_COUT
+            and c <= GATHER_MAX_CFEAT and idx.shape[2] <= 255 and first.fc.in_features == c + 3)
+
+
+def shared_mlp_grouped(layers, points, idx, grouped_xyz, xyz_first=True, pool=True):
+    """The MLP of a set-abstraction level on neighbourhoods read in place (pointnet_util.py:42-64 + 156-176 as one chain):
+    points (B,N,C) or None, idx (B,M,K) int32, grouped_xyz (B,M,K,3) centred -> (B*M, Cout) with the max over the K
+    neighbours (pool) or (B*M*K, Cout).  The first layer gathers while it stages its operand; the rest is shared_mlp's chain.
+    xyz_first: the reference's column order of the first weight, [xyz | features] (single-scale module) or [features | xyz]."""
+    layers = list(layers)
+    b, m, k = idx.shape
+    training = all(l.bn.training for l in layers)
+    first = layers[0]
+    if training and torch.is_grad_enabled():
+        z0, mean0, invstd0 = _GatherLinear.apply(points, idx, grouped_xyz.detach().contiguous(), first.fc.weight, first.fc.bias, first.bn,
+                                                 xyz_first, True)
+        params = []
+        for l in layers:
+            params += [l.fc.weight, l.fc.bias, l.bn.weight, l.bn.bias]
+        return _SharedMLPChain.apply(z0, k if pool else 0, layers, (mean0, invstd0), *params)
+    require_eval = not any(l.bn.training for l in layers)
+    assert require_eval, "shared_mlp_grouped: training-mode BatchNorm needs autograd enabled (or call .eval())"
+    # inference: running statistics; the first layer still gathers in place (its batch statistics are simply not used)
+    with torch.no_grad():
+        z0, _, _ = _GatherLinear.apply(points, idx, grouped_xyz.contiguous(), first.fc.weight, first.fc.bias, first.bn, xyz_first, False)
+    return _shared_mlp_eval(layers, z0, k if pool else 0, 0, first_done=True)
 
 
 def shared_mlp(layers, x, pool_k=0):
@@ -402,7 +525,7 @@ def shared_mlp(layers, x, pool_k=0):
         for i, l in enumerate(layers):
             w = l.fc.weight if (i or not extra) else torch.nn.functional.pad(l.fc.weight, (0, extra))
             params += [w, l.fc.bias, l.bn.weight, l.bn.bias]
-        return _SharedMLPChain.apply(x, pool_k, layers, *params)
+        return _SharedMLPChain.apply(x, pool_k, layers, None, *params)
     if bn_relu and pool_ok and not torch.is_grad_enabled() and not any(l.bn.training for l in layers):
         return _shared_mlp_eval(layers, x, pool_k, extra)
     if extra:

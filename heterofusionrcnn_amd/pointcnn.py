@@ -522,6 +522,23 @@ class SeparableK(nn.Module):
         return self.post(linear_nobias(depthwise_k(x, self.depthwise), self.pointwise.weight))
 
 
+# The X-transformation branch of an X-Conv (x0 -> x1 -> x2 on (B,P,K*3): rows = P) and its lifting branch (lift0 -> lift1 on
+# (B,P,K,3): rows = P*K) meet only in the X x F_* product (pointcnn.py:96-133).  With CONCURRENT_X_BRANCH the X branch is
+# enqueued on a side HIP stream: its ~35 small launches per layer (forward + backward: autograd runs a node's backward on the
+# stream its forward ran on) overlap the lifting branch instead of queueing behind it; inside a captured step the fork and the
+# join become edges of the graph.  Off by default; graph_step.TrainStep / bench.py switch it on below 8 frames per GPU, where
+# the kernels of one branch do not fill the chip.
+CONCURRENT_X_BRANCH = False
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 class XConv(nn.Module):
     """pointcnn.py:16-151.  pts (B,N,3), fts (B,N,Cprev) or None, qrs (B,P,3) -> (B,P,C) (+ C//4 with_global)"""
 
@@ -543,6 +560,12 @@ class XConv(nn.Module):
             self.g1 = Dense(c // 4, c // 4)
         self.out_channel = c + (c // 4 if with_global else 0)
 
+    def _x_transform(self, local, b, p, k):
+        """pointcnn.py:107-131: conv2d (1,K) over the [k][c] window, two depthwise (1,K) convolutions -> (B,P,K,K)"""
+        x = self.x0(local.reshape(b, p, 1, k * 3)).reshape(b, p, k, k)
+        x = self.x1(x).reshape(b, p, k, k)
+        return self.x2(x).reshape(b, p, k, k)
+
     def neighbours(self, pts, qrs):
         """knn_indices_general(qrs, pts, K*D)[:, :, ::D] (pointcnn.py:72-73): coordinates only"""
         with torch.no_grad():
@@ -556,6 +579,15 @@ class XConv(nn.Module):
         b, p, k = idx.shape
         local = group_point(pts, idx) - qrs.unsqueeze(2)     # (B,P,K,3)  P' <- P - p
         bn1 = self.lift1.post.bn
+        x = side = None
+        if self.with_x and CONCURRENT_X_BRANCH and local.is_cuda:
+            # fork: the X-transformation on the side stream, from `local` (made on this stream) to the (B,P,K,K) matrices
+            cur = torch.cuda.current_stream(local.device)
+            side = _side_stream(local.device)
+            side.wait_stream(cur)
+            local.record_stream(side)
+            with torch.cuda.stream(side):
+                x = self._x_transform(local, b, p, k)
         gather = self.with_x and fts is not None and _gather_fusable(local, self.lift1.linear.out_features, fts, self.conv.depthwise, inverse)
         if gather:
             f = dense_chain(self.lift0, self.lift1, local)    # F_delta alone: the neighbours' features are read in place below
@@ -570,9 +602,11 @@ class XConv(nn.Module):
             if fts is not None:
                 f = concat_group(f, fts, idx, inverse)         # F_* <- [F_delta, F]: gathered straight into the concat
         if self.with_x:
-            x = self.x0(local.reshape(b, p, 1, k * 3)).reshape(b, p, k, k)
-            x = self.x1(x).reshape(b, p, k, k)
-            x = self.x2(x).reshape(b, p, k, k)
+            if side is not None:                               # join: this stream's next kernel reads x
+                cur.wait_stream(side)
+                x.record_stream(cur)
+            else:
+                x = self._x_transform(local, b, p, k)
             # F_X <- X x F_*, then the depthwise half of the separable convolution, in one pass
             fx = (xconv_depthwise_gather(x, f, fts, idx, self.conv.depthwise, inverse) if gather
                   else xconv_depthwise(x, f, self.conv.depthwise))
@@ -659,12 +693,21 @@ class PointCnnBackbone(nn.Module):
             dec_inv = [inv(ix, pts[pi + 1].shape[1]) for ix, (k, d, pi, qi) in zip(dec_idx, self.cfg.xdconv)]
         return {"pts": pts, "enc": enc_idx, "dec": dec_idx, "enc_inv": enc_inv, "dec_inv": dec_inv}
 
-    def forward(self, xyz, features, geometry=None):
+    def forward(self, xyz, features, geometry=None, taps=None):
+        """taps (a list): filled with (output, detached copy) of every encoder layer -- each tensor that flows from the encoder
+        into the decoder; the decoder then reads the copies (see below)"""
         g = geometry if geometry is not None else self.geometry(xyz)
         pts = g["pts"]
         fts = [features]
         for li, m in enumerate(self.enc):
             fts.append(m(pts[li], fts[-1], pts[li + 1], g["enc"][li], g.get("enc_inv", [None] * len(self.enc))[li]))
+        if taps is not None:
+            # a clean cut: the decoder (and everything after it) reads detached copies that are leaves of their own graph, so
+            # d loss / d copy holds the downstream paths only; the encoder's own chain (layer i+1 reads layer i) stays on the
+            # originals, through which graph_step.TrainStep later pushes those gradients
+            cuts = [t.detach().requires_grad_(True) for t in fts[1:]]
+            taps.extend(zip(fts[1:], cuts))
+            fts = [fts[0]] + cuts
         cur = None
         for li, (k, d, pi, qi) in enumerate(self.cfg.xdconv):
             src = fts[pi + 1] if li == 0 else cur

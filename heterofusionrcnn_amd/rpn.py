@@ -170,7 +170,14 @@ class _SALevelModule(nn.Module):
     def forward(self, xyz, points, geom=None):
         new_xyz, per_scale = geom if geom is not None else self.geometry(xyz)
         outs = []
+        from . import modules as _modules
+        from .mlp import grouped_mlp_fusable, shared_mlp_grouped
         for (idx, grouped_xyz), mlp in zip(per_scale, self.mlps):
+            live = all(l.bn.training for l in mlp) and torch.is_grad_enabled() or not any(l.bn.training for l in mlp)
+            if _modules.GATHER_ON_LOAD and xyz.is_cuda and live and grouped_mlp_fusable(list(mlp), points, idx):
+                # the first layer reads the neighbourhoods in place: no (B,M,K,C+3) tensor
+                outs.append(shared_mlp_grouped(list(mlp), points, idx, grouped_xyz, xyz_first=not self.msg).reshape(idx.shape[0], idx.shape[1], -1))
+                continue
             grouped = group_concat(points, idx, grouped_xyz, xyz_last=self.msg)    # one pass, rows padded to 4 columns
             bsz, npt, k, cin = grouped.shape
             outs.append(shared_mlp(mlp, grouped.reshape(-1, cin), pool_k=k).reshape(bsz, npt, -1))
@@ -439,10 +446,11 @@ class RpnModel(nn.Module):
     def geometry(self, xyz):
         return self.backbone.geometry(xyz)
 
-    def forward(self, xyz, intensity, geometry=None, img_fts=None, calib=None):
+    def forward(self, xyz, intensity, geometry=None, img_fts=None, calib=None, taps=None):
         """xyz (B,P,3), intensity (B,P,1) -> seg logits (B,P,K+1), head (B,P,K,D).  img_fts (B,H,W,C) + calib (B,3,4) feed
-        the fusion when the config has one."""
-        pc_fts = self.backbone(xyz, intensity, geometry)
+        the fusion when the config has one.  taps (a list, PointCNN backbone only): receives (output, detached copy) of every encoder
+        layer -- the tensors that separate the encoder from everything after it (graph_step.TrainStep cuts the backward pass there)."""
+        pc_fts = self.backbone(xyz, intensity, geometry, taps=taps) if taps is not None else self.backbone(xyz, intensity, geometry)
         proj = None
         if self.cfg.fusion != "none":
             proj = project_gather(xyz, calib, img_fts)
@@ -485,6 +493,30 @@ class RpnModel(nn.Module):
         with torch.no_grad():
             targets = rpn_targets(self.cfg, xyz, label_cls, label_reg)
         return rpn_loss(self.cfg, seg_logits, head, label_cls, targets)
+
+
+class RpnWithImageBranch(nn.Module):
+    """The whole rpn_multiclass step of hf/core/models/rpn_model.py:126-127,223: the VGG pyramid (inference.ImgVggPyr, a stock
+    convolutional network on the vendor library -- no custom op, outside SURVEY 8's kernel scope) in front of the fusion, trained with
+    the RPN.  `img_fts` of forward() is then the IMAGE (B,H,W,3); everything else is RpnModel's interface."""
+
+    def __init__(self, rpn: "RpnModel", img_net: nn.Module):
+        super().__init__()
+        self.rpn, self.img_net = rpn, img_net
+        self.cfg = rpn.cfg
+
+    @property
+    def backbone(self):
+        return self.rpn.backbone
+
+    def geometry(self, xyz):
+        return self.rpn.geometry(xyz)
+
+    def forward(self, xyz, intensity, geometry=None, img_fts=None, calib=None, **kw):
+        return self.rpn(xyz, intensity, geometry=geometry, img_fts=self.img_net(img_fts), calib=calib, **kw)
+
+    def loss(self, *args, **kw):
+        return self.rpn.loss(*args, **kw)
 
 
 def synthetic_ground_truth(rng, batch, boxes_per_frame, cfg: RpnConfig, extent=((-40.0, 40.0), (0.0, 70.0)), ground_y=1.6):

@@ -512,6 +512,23 @@ int hf_xconv_depthwise_gather_grad(int b, int n_src, int rows_per_cloud, int k, 
                                    float *grad_f_delta, float *grad_fts, float *grad_wd, void *workspace, size_t workspace_bytes,
                                    hf_stream_t stream);
 
+/* The FIRST layer of a set-abstraction MLP on neighbourhoods read in place: sample_and_group
+ * (hf/core/feature_extractors/pointnet_util.py:42-64) materialises new_points (B,M,K,C+3) = [grouped_xyz - centre | points[idx]] and
+ * the first tf_util.conv2d (:156-160) reads it back; here the operand rows are assembled from (points, idx, grouped_xyz) while
+ * they are staged for the MFMA tiles, so that tensor never exists.  rows = B*M*K, rows_per_cloud = M*K, points (B,n_src,c_feat)
+ * (NULL when c_feat == 0), idx (rows) int32, grouped_xyz (rows,3) = query_ball_group's centred coordinates.
+ * Column layout of the assembled operand, which `weight` (cout, cin) / `grad_weight` follow:
+ *   [feature 0 .. c_feat-1, zeros up to cfp = round_up(c_feat, 4) | x, y, z, 0]      cin = cfp + 4
+ * (the caller permutes / pads the layer's weight once per step: a few KB).  Otherwise as hf_linear_bn_fwd / hf_linear_wgrad:
+ * z (rows,cout) = operand weight^T + bias with the batch statistics of z from the accumulators; grad_weight = grad_z^T operand. */
+int hf_linear_bn_fwd_gather(long long rows, int c_feat, int cout, const float *points, int n_src, long long rows_per_cloud,
+                            const int *idx, const float *grouped_xyz, const float *weight, const float *bias, float *z, float eps,
+                            float momentum, float *running_mean, float *running_var, float *mean, float *invstd, void *workspace,
+                            size_t workspace_bytes, hf_stream_t stream);
+int hf_linear_wgrad_gather(long long rows, int cout, int c_feat, const float *grad_z, const float *points, int n_src,
+                           long long rows_per_cloud, const int *idx, const float *grouped_xyz, float *grad_weight,
+                           void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
 /* ------------------------------------------------------------------ the optimizer step of the train step */
 
 /* tf.train.AdamOptimizer.apply_gradients over EVERY parameter tensor in one launch (hf/core/trainer.py:71,

@@ -1,0 +1,43 @@
+"""profiles/bev_iou_alu.json: the ALU-bound fraction of compute_bev_iou at 70 000 x 64 (BASELINE.md section 3 asks for the HBM- and the
+ALU-bound fraction) from one rocprofv3 --pmc pass + one --kernel-trace pass of scripts/bev_nms_kernels.py, stamped with the hash of
+bev_iou.hip: bench.py prints `bev_iou_frac_alu_bound` only while the stamp matches the source in the tree.
+  alu fraction = SQ_INSTS_VALU x 4 cycles (a wave64 vector instruction occupies its SIMD16 for 4 cycles) / (1024 SIMDs x kernel cycles),
+  kernel cycles = GRBM_GUI_ACTIVE of the dispatch (the shader clock while the kernel runs)
+usage: python scripts/make_alu_json.py <pmc_dir> <trace_dir> <out.json>"""
+import csv, glob, hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def stamp():
+    with open(os.path.join(ROOT, "heterofusionrcnn_amd", "csrc", "bev_iou.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def med(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+pm, tr, out = sys.argv[1:4]
+ctr = {}
+for f in glob.glob(os.path.join(pm, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "bev_iou_kernel" in r["Kernel_Name"]:
+            ctr.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            ctr[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+dur = []
+for f in glob.glob(os.path.join(tr, "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "bev_iou_kernel" in r["Kernel_Name"]:
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+c = {k: med(list(v.values())) for k, v in ctr.items()}
+us = med(dur)
+cycles = c.get("GRBM_GUI_ACTIVE")
+res = {"kernel": "hf::bev_iou_kernel (hf_compute_bev_iou), 70000 x 64", "kernel_source_stamp": stamp(), "counters_median_per_launch": c,
+       "kernel_us_median_isolated": round(us, 2), "launches": len(dur),
+       "shader_clock_ghz_during_kernel": round(cycles / (us * 1e3), 3) if cycles else None,
+       "alu_bound_frac": round(c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles), 4) if cycles else None,
+       "formula": "SQ_INSTS_VALU * 4 cycles / (1024 SIMDs * GRBM_GUI_ACTIVE cycles)",
+       "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE + --kernel-trace of scripts/bev_nms_kernels.py"}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res))

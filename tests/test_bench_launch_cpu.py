@@ -22,9 +22,11 @@ def _run(*flags):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("scaling,per_rank", [("weak", 8), ("strong", 4)])
+@pytest.mark.parametrize("scaling,per_rank", [("weak", 8), ("strong", 4), (None, 4)])
 def test_self_launch_two_ranks(scaling, per_rank):
-    r = _run("--gpus", "2", "--scaling", scaling)
+    """the default is BASELINE config 4's shape: a GLOBAL batch of 8 frames over the ranks (strong scaling)"""
+    r = _run("--gpus", "2", *(("--scaling", scaling) if scaling else ()))
+    scaling = scaling or "strong"
     assert r["n_gpus"] == 2 and r["ranks"] == 2 and r["steps"] == 3 and r["warmup"] == 1
     assert r["scaling"] == scaling and r["config"]["frames_per_gpu"] == per_rank
     assert r["config"]["global_batch"] == 2 * per_rank and r["value"] > 0

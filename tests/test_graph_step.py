@@ -106,6 +106,75 @@ def test_flat_gradient_all_reduce_two_ranks_gloo():
     assert torch.allclose(ret[0]["params"], ref, rtol=1e-5, atol=1e-6)
 
 
+class _ToyBackbone(nn.Module):
+    """an encoder with skip connections into a decoder, the interface TrainStep cuts at: backbone.enc + forward(..., taps=)"""
+
+    def __init__(self):
+        super().__init__()
+        self.enc = nn.ModuleList([nn.Linear(4, 8), nn.Linear(8, 8)])
+        self.dec = nn.Linear(16, 6)
+
+    def forward(self, xyz, intensity, geometry=None, taps=None):
+        f1 = torch.tanh(self.enc[0](torch.cat([xyz, intensity], -1)))
+        f2 = torch.tanh(self.enc[1](f1))
+        if taps is not None:                                   # the decoder reads detached copies (a clean cut)
+            c1, c2 = f1.detach().requires_grad_(True), f2.detach().requires_grad_(True)
+            taps.extend([(f1, c1), (f2, c2)])
+            f1, f2 = c1, c2
+        return self.dec(torch.cat([f1, f2], -1))              # BOTH encoder outputs cross the cut
+
+
+class _ToyRpn(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = _ToyBackbone()
+        self.head = nn.Linear(6, 2)
+
+    def forward(self, xyz, intensity, geometry=None, img_fts=None, calib=None, taps=None):
+        f = self.backbone(xyz, intensity, geometry, taps=taps)
+        return self.head(f), f
+
+    def loss(self, xyz, seg_logits, head, label_cls, label_reg):
+        return ((seg_logits - label_reg[..., :2]) ** 2).mean() + 0.1 * (head ** 2).mean(), None
+
+
+def _split_worker(rank, world, port, ret):
+    from heterofusionrcnn_amd import dp
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ctx = dp.init(backend="gloo")
+    g = torch.Generator().manual_seed(5)
+    xyz, inten, reg = torch.randn(8, 7, 3, generator=g), torch.randn(8, 7, 1, generator=g), torch.randn(8, 7, 7, generator=g)
+    mine = dp.shard_frames(8, rank, world)
+    out = {}
+    for overlap in (True, False):
+        torch.manual_seed(11 + rank)
+        model = _ToyRpn()
+        broadcast_parameters(model)
+        opt = torch.optim.SGD(model.parameters(), lr=dp.scaled_lr(0.05, world))
+        inputs = {"xyz": xyz[mine], "intensity": inten[mine], "label_cls": None, "label_reg": reg[mine]}
+        step = TrainStep(model, opt, inputs, geometry={}, world=world, graph=False, overlap_exchange=overlap)
+        assert step.split == overlap and step.chunks == (2 if overlap else 1)
+        if overlap:                                            # chunk 0 = everything after the encoder, chunk 1 = the encoder
+            enc = {id(p) for p in model.backbone.enc.parameters()}
+            assert [id(p) in enc for p in step.grads.params] == [False] * len(step.late) + [True] * len(step.early)
+        losses = [float(step()) for _ in range(4)]
+        out[overlap] = (torch.cat([p.detach().flatten() for p in model.parameters()]), losses)
+    ret[rank] = out
+    dp.shutdown(ctx)
+
+
+def test_chunked_gradient_exchange_two_ranks_gloo():
+    """the backward pass cut at the encoder's outputs, the late parameters' chunk of the flat buffer
+    reduced while the encoder's backward runs, then the encoder's chunk -- same trajectory as the single exchange, on both ranks"""
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_split_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.allclose(ret[r][True][0], ret[r][False][0], rtol=1e-5, atol=1e-6)
+        assert np.allclose(ret[r][True][1], ret[r][False][1], rtol=1e-5)
+    assert torch.equal(ret[0][True][0], ret[1][True][0])
+
+
 def test_tree_tensors_order_is_stable():
     geo = {"pts": [torch.zeros(1), torch.ones(2)], "enc": (torch.ones(3),), "dec": []}
     a = [t.numel() for t in tree_tensors(geo)]
@@ -177,6 +246,31 @@ def test_graph_replay_reproduces_the_eager_trajectory():
     assert e[-1] < 0.9 * e[0] and g[-1] < 0.9 * g[0], (e, g)
     np.testing.assert_allclose(g, e, rtol=2e-2)
     np.testing.assert_allclose(g[:3], e[:3], rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_x_branch_on_a_side_stream_gives_the_same_step(graph):
+    """pointcnn.CONCURRENT_X_BRANCH: the X-transformation branch of every X-Conv enqueued on a side HIP stream (forward and, through
+    autograd's stream bookkeeping, backward) must not change a step: same losses over 6 steps, eager and replayed"""
+    from heterofusionrcnn_amd import pointcnn, rpn as R_
+    cfg = _small_multiclass()
+    inp = _frames(cfg, 2, 2048, seed=3)
+    losses = {}
+    for flag in (False, True):
+        pointcnn.CONCURRENT_X_BRANCH = flag
+        try:
+            torch.manual_seed(9)
+            model = R_.RpnModel(cfg).cuda().train()
+            opt = torch.optim.Adam(model.parameters(), lr=2e-3, fused=True, capturable=True)
+            geo = model.geometry(inp["xyz"])
+            step = TrainStep(model, opt, inp, geo, world=1, graph=graph, warmup=2)
+            losses[flag] = [float(step(geometry=geo)) for _ in range(6)]
+            torch.cuda.synchronize()
+        finally:
+            pointcnn.CONCURRENT_X_BRANCH = False
+    np.testing.assert_allclose(losses[True], losses[False], rtol=2e-4)
+    assert losses[True][-1] < losses[True][0]
 
 
 @pytest.mark.gpu
