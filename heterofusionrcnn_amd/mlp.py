@@ -473,15 +473,19 @@ class _GatherLinear(torch.autograd.Function):
 
 GATHER_MAX_COUT = 256           # accumulator tiles of the MFMA forward kernel
 GATHER_MAX_CFEAT = 1020
+# below this many feature channels the (B,M,K,C+3) tensor is a few columns wide and cheaper to write once than to gather one
+# 4-byte feature per neighbour behind its index (level 1 of config 2, C = 1: +210 us in place; level 2, C = 64: equal time, -170 MB
+# of traffic -- profiles/r04_sa_gather_traffic.txt)
+GATHER_MIN_CFEAT = 16
 
 
-def grouped_mlp_fusable(layers, points, idx):
+def grouped_mlp_fusable(layers, points, idx, min_cfeat=0):
     """shared_mlp_grouped's conditions: BatchNorm + ReLU on every layer, on the device, first layer within the MFMA kernel's
-    range (Cout <= 256), pool_k <= 255"""
+    range (Cout <= 256), pool_k <= 255; min_cfeat: the callers that CHOOSE between the routes pass GATHER_MIN_CFEAT"""
     first = layers[0]
     c = points.shape[2] if points is not None else 0
     return (idx.is_cuda and all(l.bn is not None and l.bn.relu for l in layers) and first.fc.out_features <= GATHER_MAX_COUT
-            and c <= GATHER_MAX_CFEAT and idx.shape[2] <= 255 and first.fc.in_features == c + 3)
+            and min_cfeat <= c <= GATHER_MAX_CFEAT and idx.shape[2] <= 255 and first.fc.in_features == c + 3)
 
 
 def shared_mlp_grouped(layers, points, idx, grouped_xyz, xyz_first=True, pool=True):

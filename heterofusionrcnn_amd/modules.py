@@ -23,7 +23,7 @@ from .grouping import group_concat, group_point, knn_point, query_ball_group, qu
 from .interpolate import (INVERSE_MAX_KNOWN, three_interpolate, three_interpolate_concat, three_nn,
                           three_nn_inverse)
 from .sampling import farthest_point_sample, gather_point
-from .mlp import BatchNormReLU, grouped_mlp_fusable, linear_bn_relu, shared_mlp, shared_mlp_grouped
+from .mlp import GATHER_MIN_CFEAT, BatchNormReLU, grouped_mlp_fusable, linear_bn_relu, shared_mlp, shared_mlp_grouped
 
 # the first layer of a set-abstraction MLP gathers its operand in place (mlp.shared_mlp_grouped); False keeps the
 # materialised group_concat route (tests compare the two)
@@ -171,7 +171,7 @@ class PointnetSAModule(nn.Module):
             # coordinates are inputs in every reference model: the feature-independent half runs without autograd
             new_xyz, idx, grouped_xyz = geom if geom is not None else self.geometry(xyz)
             if (GATHER_ON_LOAD and self.pooling == "max" and (self.use_xyz or points is None) and xyz.is_cuda
-                    and grouped_mlp_fusable(self.mlp, points, idx)
+                    and grouped_mlp_fusable(self.mlp, points, idx, GATHER_MIN_CFEAT)
                     and (all(l.bn.training for l in self.mlp) and torch.is_grad_enabled() or not any(l.bn.training for l in self.mlp))):
                 # idx -> gather -> centre -> MLP -> max as one chain; the grouped (B,M,K,C+3) tensor of
                 # pointnet_util.py:58-60 is never written (the first layer reads the neighbourhoods in place)
@@ -242,7 +242,7 @@ class PointnetSAModuleMSG(nn.Module):
         for radius, nsample, mlp in zip(self.radius_list, self.nsample_list, self.mlps):
             idx, _, grouped_xyz = query_ball_group(radius, nsample, xyz, new_xyz, center=True)
             if (GATHER_ON_LOAD and (self.use_xyz or points is None) and not xyz.requires_grad and xyz.is_cuda
-                    and grouped_mlp_fusable(mlp, points, idx)
+                    and grouped_mlp_fusable(mlp, points, idx, GATHER_MIN_CFEAT)
                     and (all(l.bn.training for l in mlp) and torch.is_grad_enabled() or not any(l.bn.training for l in mlp))):
                 outs.append(shared_mlp_grouped(mlp, points, idx, grouped_xyz, xyz_first=False).reshape(idx.shape[0], idx.shape[1], -1))
                 continue

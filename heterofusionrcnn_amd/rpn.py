@@ -171,10 +171,10 @@ class _SALevelModule(nn.Module):
         new_xyz, per_scale = geom if geom is not None else self.geometry(xyz)
         outs = []
         from . import modules as _modules
-        from .mlp import grouped_mlp_fusable, shared_mlp_grouped
+        from .mlp import GATHER_MIN_CFEAT, grouped_mlp_fusable, shared_mlp_grouped
         for (idx, grouped_xyz), mlp in zip(per_scale, self.mlps):
             live = all(l.bn.training for l in mlp) and torch.is_grad_enabled() or not any(l.bn.training for l in mlp)
-            if _modules.GATHER_ON_LOAD and xyz.is_cuda and live and grouped_mlp_fusable(list(mlp), points, idx):
+            if _modules.GATHER_ON_LOAD and xyz.is_cuda and live and grouped_mlp_fusable(list(mlp), points, idx, GATHER_MIN_CFEAT):
                 # the first layer reads the neighbourhoods in place: no (B,M,K,C+3) tensor
                 outs.append(shared_mlp_grouped(list(mlp), points, idx, grouped_xyz, xyz_first=not self.msg).reshape(idx.shape[0], idx.shape[1], -1))
                 continue
