@@ -29,6 +29,8 @@
 // candidate and the order by the data index alone.
 #include <math.h>
 
+#include <type_traits>
+
 #include "bq_common.h"
 
 namespace hf {
@@ -331,7 +333,19 @@ __global__ __launch_bounds__(kQueryThreads) void bq_query_kernel(int n, int m, i
         // ---- few-hit path (the usual case): every hit travels with its coordinates through LDS to the owner lane of its query,
         // which keeps up to kHitCap of them sorted by index; the rows are then written from LDS alone ----
         const unsigned long long anyhit = __ballot(nh > 0);
-        if (nh > 0) { stage4[2 * t] = hv0; if (nh > 1) stage4[2 * t + 1] = hv1; }
+        // the hits travel ALREADY CENTRED (x - qx, y - qy, z - qz, index): the lane that found a hit holds its query's centre, and the
+        // same fp32 subtraction done here once per hit is not done once per output element in the store loop below (which was
+        // 260 of the wave's ~400 vector instructions: centre fetched through three cross-lane reads and subtracted per element,
+        // a select against the empty-row fallback per component -- the kernel is vector-issue-bound, profiles/r04_bq_query_pmc.txt)
+        auto centred = [&](u4 v) -> u4 {
+            if (GROUP && center) {
+                v.x = __float_as_uint(__uint_as_float(v.x) - qx);
+                v.y = __float_as_uint(__uint_as_float(v.y) - qy);
+                v.z = __float_as_uint(__uint_as_float(v.z) - qz);
+            }
+            return v;
+        };
+        if (nh > 0) { stage4[2 * t] = centred(hv0); if (nh > 1) stage4[2 * t + 1] = centred(hv1); }
         if (nh > 0) stage[8 * t + 7] = nh > 1 ? static_cast<int>(hv1.w) : -1;    // .w of the second slot: -1 = one hit only
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         asm volatile("" ::: "memory");
@@ -357,6 +371,14 @@ __global__ __launch_bounds__(kQueryThreads) void bq_query_kernel(int n, int m, i
                 }
             }
             hits[qi] = min(total, nsample);
+            if (GROUP && total == 0) {
+                // a row without hits is index 0 everywhere: its coordinates are point 0 of the cloud (minus the centre); filed as the
+                // row's entry 0, so that the store loop needs no special case (rare: a query that is no point of its own cloud)
+                const P3 p0 = load_p3(rcloud, 0u);
+                mine[0] = centred(u4{ __float_as_uint(p0.x), __float_as_uint(p0.y), __float_as_uint(p0.z), 0u });
+            } else if (!GROUP && total == 0) {
+                mine[0] = u4{ 0u, 0u, 0u, 0u };
+            }
         }
         if (__ballot(total > kHitCap) == 0ull) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -368,37 +390,31 @@ __global__ __launch_bounds__(kQueryThreads) void bq_query_kernel(int n, int m, i
                 const __amdgpu_buffer_rsrc_t rc = make_rsrc(pts_cnt + jbase, static_cast<unsigned>(nqw) * 4u);
                 store_i32<SM>(rc, lane, hits[qw0 + (lane < nqw ? lane : 0)]);   // lanes >= nqw: dropped by the range check
             }
-            // a row without hits is index 0 everywhere: its coordinates are point 0 of the cloud
-            P3 p0 = { 0.f, 0.f, 0.f };
-            if (GROUP && __ballot(lane < nqw && hits[qw0 + (lane < nqw ? lane : 0)] == 0) != 0ull) p0 = load_p3(rcloud, 0u);
-            for (int e0 = lane; e0 - lane < total_e; e0 += 256) {   // wave-uniform trip count: the centre comes from another lane
-                int ki[4];
-                float v[4][3];
+            // four elements per lane and pass: the LDS reads first, then the stores; every store instruction of the wave covers one
+            // contiguous range (256 bytes of idx, 768 bytes of grouped_xyz).  POW2: nsample is a power of two (every shipped
+            // config): element -> (query, column) is a shift and a mask, decided once for the loop
+            auto write_rows = [&](auto pow2_tag) {
+                constexpr bool POW2 = decltype(pow2_tag)::value;
+                for (int e0 = lane; e0 - lane < total_e; e0 += 256) {
+                    u4 hv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = e0 + 64 * i;
-                    const int ee = e < total_e ? e : 0;
-                    const int qq = ns_shift >= 0 ? (ee >> ns_shift) : (ee / nsample);
-                    const int col = ee - qq * nsample;
-                    const int h = hits[qw0 + qq];
-                    const u4 hv = hl[(qw0 + qq) * kHitCap + (col < h ? col : 0)];
-                    ki[i] = h == 0 ? 0 : static_cast<int>(hv.w);
-                    if (GROUP) {
-                        float vx = h == 0 ? p0.x : __uint_as_float(hv.x), vy = h == 0 ? p0.y : __uint_as_float(hv.y), vz = h == 0 ? p0.z : __uint_as_float(hv.z);
-                        if (center) {
-                            const float cx = __shfl(qx, (qq * G) & 63), cy = __shfl(qy, (qq * G) & 63), cz = __shfl(qz, (qq * G) & 63);
-                            vx = vx - cx; vy = vy - cy; vz = vz - cz;
-                        }
-                        v[i][0] = vx; v[i][1] = vy; v[i][2] = vz;
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = e0 + 64 * i;
+                        const int ee = e < total_e ? e : 0;
+                        const int qq = POW2 ? (ee >> ns_shift) : (ee / nsample);
+                        const int col = POW2 ? (ee & (nsample - 1)) : (ee - qq * nsample);
+                        const int h = max(hits[qw0 + qq], 1);                   // an empty row reads its entry 0 (point 0, index 0)
+                        hv[i] = hl[(qw0 + qq) * kHitCap + (col < h ? col : 0)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = e0 + 64 * i;   // e >= total_e: dropped by the range check of the descriptor
+                        if (idx) store_i32<SM>(ri, e, static_cast<int>(hv[i].w));
+                        if (GROUP) store_p3<SM>(rg, e, __uint_as_float(hv[i].x), __uint_as_float(hv[i].y), __uint_as_float(hv[i].z));
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = e0 + 64 * i;   // e >= total_e: dropped by the range check of the descriptor
-                    if (idx) store_i32<SM>(ri, e, ki[i]);
-                    if (GROUP) store_p3<SM>(rg, e, v[i][0], v[i][1], v[i][2]);
-                }
-            }
+            };
+            if (ns_shift >= 0) write_rows(std::true_type{}); else write_rows(std::false_type{});
             return;
         }
         // some query of this wave has more than kHitCap hits: the general path below (rows of entries; the staging area is
