@@ -662,6 +662,130 @@ constexpr int kSweepThreads = 1024;
 constexpr int kSweepGatherers = kSweepThreads - 64;
 constexpr int kSweepLead = 4;   // steps between the request of a column's first entries and their use
 
+// The streaming sweep.  The barrier form above pays one 1024-thread barrier plus ~5 dependent LDS round trips per column block
+// (0.55 us x 141 blocks at 9000 boxes) although what a block needs from memory -- the entries filed under its column, its
+// diagonal and next words -- depends on NO decision.  Here waves 1..15 only MOVE list entries from memory into an LDS ring, as
+// far ahead as the ring allows (a flag per column says "complete"), and wave 0 alone walks the blocks: for block b it ORs the
+// words of the ring entries whose row was kept (rows <= b-2: all decided), adds the next words of the boxes kept in block b-1,
+// resolves the block by the whole-wave fixed point, publishes how far the ring has been consumed.  No workgroup barrier inside
+// the walk; every wait is on an LDS word that another wave is bound to write (producers fill columns in increasing order, space
+// in the ring is granted in column order, the consumer takes columns in order), so every wave reaches the end.
+constexpr int kStreamMaxBlocks = 1024;      // 65 536 boxes: keptw + cnts + pref + ready = 20 KB
+constexpr int kStreamRing = 8192;           // entries (128 KB, a power of two): four full columns
+constexpr int kStreamAhead = 4;             // blocks whose diagonal / next words wave 0 holds in registers
+
+__device__ __forceinline__ int lds_load_i32(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ void sweep_stream(int n, int cb, const int *__restrict__ counts, const NmsEntry *__restrict__ lists,
+                             const unsigned long long *__restrict__ diagt, const unsigned long long *__restrict__ nextw,
+                             int *__restrict__ keep, unsigned char *smem_raw, int *kept_total, int *consumed_pref, int *scan_ws)
+{
+    unsigned long long *keptw = reinterpret_cast<unsigned long long *>(smem_raw);          // cb   kept bits per block
+    int *cnts = reinterpret_cast<int *>(keptw + cb);                                         // cb   entries filed under the block
+    int *pref = cnts + cb;                                                                   // cb + 1   entries before the block
+    int *ready = pref + cb + 1;                                                              // cb   the block's entries are in the ring
+    NmsEntry *ring = reinterpret_cast<NmsEntry *>((reinterpret_cast<uintptr_t>(ready + cb) + 15) & ~static_cast<uintptr_t>(15));
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // exclusive prefix of the counts (cb <= 1024 = one value per thread)
+    {
+        const int c = t < cb ? counts[t] : 0;
+        int total = 0;
+        const int ex = block_exclusive_scan(c, scan_ws, &total);
+        if (t < cb) { cnts[t] = c; pref[t] = ex; ready[t] = 0; keptw[t] = 0ull; }
+        if (t == 0) { pref[cb] = total; *kept_total = 0; *consumed_pref = 0; }
+    }
+    __syncthreads();
+    if (wave > 0) {
+        // ---------------- producers: columns wave-1, wave-1+15, ... in increasing order ----------------
+        for (int col = wave - 1; col < cb; col += kSweepThreads / 64 - 1) {
+            const int cnt = cnts[col];
+            if (cnt == 0) continue;   // the consumer does not wait for an empty column
+            const int base = pref[col];
+            while (base + cnt - lds_load_i32(consumed_pref) > kStreamRing) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+            const NmsEntry *src = lists + static_cast<size_t>(col) * kNmsListCap;
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<NmsEntry *>(src), 0, cnt * 16, 0x00020000);
+            for (int k0 = 0; k0 < cnt; k0 += 64 * 4) {   // four 16-byte loads in flight per lane (past the end: zeros, not stored)
+                u4v e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (k0 + 64 * j + lane) * 16, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + 64 * j + lane;
+                    if (k < cnt) *reinterpret_cast<u4v *>(&ring[(base + k) & (kStreamRing - 1)]) = e[j];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's ring writes are done (the LDS keeps a wave's order)
+            if (lane == 0) __hip_atomic_store(&ready[col], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    // ---------------- consumer: wave 0 ----------------
+    __builtin_amdgcn_s_setprio(3);
+    unsigned long long dg[kStreamAhead], nx[kStreamAhead];   // diagonal word of box blk*64+lane, next word of box (blk-1)*64+lane
+    auto fetch = [&](int blk, unsigned long long &d, unsigned long long &x) {
+        const int i = blk * 64 + lane;
+        d = (blk < cb && i < n) ? diagt[i] : 0ull;
+        x = (blk >= 1 && blk < cb) ? nextw[i - 64] : 0ull;   // boxes of block blk-1 all exist
+    };
+#pragma unroll
+    for (int j = 0; j < kStreamAhead; ++j) fetch(j, dg[j], nx[j]);
+    int total_kept = 0;
+    auto step = [&](int blk, unsigned long long &d, unsigned long long &x) {
+        const int lim = min(64, n - blk * 64);
+        const unsigned long long valid = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
+        // (1) the words of the column's entries whose row was kept
+        unsigned long long acc = 0ull;
+        const int cnt = cnts[blk];
+        if (cnt > 0) {
+            while (lds_load_i32(&ready[blk]) == 0) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const int base = pref[blk];
+            for (int k = lane; k < cnt; k += 64) {
+                const NmsEntry e = ring[(base + k) & (kStreamRing - 1)];
+                if ((keptw[e.row >> 6] >> (e.row & 63)) & 1ull) acc |= e.word;
+            }
+        }
+        // (2) the next words of the boxes kept in block blk-1
+        if (blk > 0 && ((keptw[blk - 1] >> lane) & 1ull)) acc |= x;
+        // OR over the wave: few lanes hold anything
+        unsigned long long remv = 0ull;
+        for (unsigned long long m = __ballot(acc != 0ull); m; m &= m - 1ull) {
+            const int src = __builtin_ctzll(m);
+            const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<unsigned>(acc)), src));
+            const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<unsigned>(acc >> 32)), src));
+            remv |= (static_cast<unsigned long long>(hi) << 32) | lo;
+        }
+        // (3) resolve: kept[l] = alive[l] and no kept killer (fixed point over the wave, as in the barrier form)
+        const unsigned long long killers = lane < lim ? d : 0ull;
+        const unsigned long long alive = ~remv & valid;
+        unsigned long long kb = alive;
+        for (;;) {
+            const unsigned long long next = alive & ~__ballot((killers & kb) != 0ull);
+            if (next == kb) break;
+            kb = next;
+        }
+        if ((kb >> lane) & 1ull) keep[total_kept + __builtin_popcountll(kb & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+        total_kept += __builtin_popcountll(kb);
+        if (lane == 0) {
+            keptw[blk] = kb;
+            __hip_atomic_store(consumed_pref, pref[blk + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // the ring up to here is free
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // keptw[blk] is visible to this wave's next reads (same wave: in order anyway)
+        fetch(blk + kStreamAhead, d, x);
+    };
+    static_assert(kStreamAhead == 4, "four register sets rotate below");
+    for (int base = 0; base < cb; base += 4) {
+        step(base, dg[0], nx[0]);
+        if (base + 1 < cb) step(base + 1, dg[1], nx[1]);
+        if (base + 2 < cb) step(base + 2, dg[2], nx[2]);
+        if (base + 3 < cb) step(base + 3, dg[3], nx[3]);
+    }
+    if (lane == 0) *kept_total = total_kept;
+}
+
 __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, int chunk_blocks, const unsigned char *__restrict__ ws_base,
                                                                   size_t ws_stride, int *__restrict__ keep,
                                                                   int *__restrict__ num_kept)
@@ -683,7 +807,25 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, int chu
     unsigned long long *remv = keptw + cb;                                          // cb: removal word per block
     int *cnts = reinterpret_cast<int *>(remv + cb);                                 // cb: entries filed under the block
     __shared__ int kept_total;
+    __shared__ int any_overflow, consumed_pref, scan_ws[32];
     const int t = threadIdx.x;
+    // ---- the streaming form (round 4): no barrier per column block.  Taken when no column's list overflowed and the per-block
+    // arrays plus the entry ring fit in LDS (cb <= kStreamMaxBlocks = 65 536 boxes); else the barrier form below. ----
+    if (t == 0) any_overflow = 0;
+    __syncthreads();
+    if (cb <= kStreamMaxBlocks) {
+        for (int w = t; w < cb; w += kSweepThreads)
+            if (counts[w] > kNmsListCap) any_overflow = 1;
+    }
+    __syncthreads();
+    if (cb <= kStreamMaxBlocks && !any_overflow) {
+        sweep_stream(n, cb, counts, lists, diagt, nextw, keep, smem_raw, &kept_total, &consumed_pref, scan_ws);
+        __syncthreads();
+        const int kept_s = kept_total;
+        for (int p = kept_s + t; p < n; p += kSweepThreads) keep[p] = 0;   // pad with keep[0] (bev_iou.cpp:110-112)
+        if (t == 0 && num_kept) *num_kept = kept_s;
+        return;
+    }
     for (int w = t; w < cb; w += kSweepThreads) { remv[w] = 0ull; keptw[w] = 0ull; cnts[w] = counts[w]; }
     if (t == 0) kept_total = 0;
     // every chunk_blocks steps all threads load the word pairs of the next chunk: wave 0 never waits for memory
@@ -856,8 +998,10 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
     const int cb = (n + 63) / 64;
     // LDS: kept bits + removal words per block, and the diagonal words of a chunk of blocks (all of them up to 8192 boxes)
     const int chunk_blocks = std::min(cb, 64);   // (transposed diagonal, next) word pairs of 4096 boxes: 64 KB
-    const size_t lds = sizeof(unsigned long long) * (2 * static_cast<size_t>(cb) + 2 * 64 * static_cast<size_t>(chunk_blocks)) + sizeof(int) * static_cast<size_t>(cb);
+    size_t lds = sizeof(unsigned long long) * (2 * static_cast<size_t>(cb) + 2 * 64 * static_cast<size_t>(chunk_blocks)) + sizeof(int) * static_cast<size_t>(cb);
     if (cb > 8192 || lds > 160 * 1024 - 256) return HF_EINVAL;   // n <= 524 288 boxes (pre_nms_size is 9000)
+    if (cb <= kStreamMaxBlocks)   // the streaming sweep: per-block arrays + the ring of list entries
+        lds = std::max(lds, sizeof(unsigned long long) * cb + sizeof(int) * (3 * static_cast<size_t>(cb) + 1) + 16 + sizeof(NmsEntry) * kStreamRing);
     hipStream_t st = as_stream(stream);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     const size_t ws_stride = nms_ws_bytes(n);

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-4 evidence set; run on the GPU box (via gpurun) from the repo root.  Outputs under gpurun_out/evidence4/ (copied into
+# profiles/ as r04_* afterwards).
+set -o pipefail
+OUT=$GRAFT_REPO_ROOT/gpurun_out/evidence4
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout -k 10 500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; rc=$?
+echo "pytest exit $rc" >> $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -1 $OUT/smoke.log
+timeout -k 10 1000 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
+python scripts/probes/show_bench.py $OUT/bench.json | cut -c1-400
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-table --no-side-runs > $OUT/bench_prof.log 2>&1; echo "rocprof bench exit $?"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_roofline -o roofline -- python3 scripts/roofline_kernel.py > $OUT/roofline_trace.log 2>&1; echo "rocprof roofline exit $?"
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 scripts/roofline_kernel.py > $OUT/pmc_fetch.log 2>&1 && \
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 scripts/roofline_kernel.py > $OUT/pmc_write.log 2>&1; echo "pmc exit $?"
+python scripts/make_traffic_json.py $OUT/pmc_fetch $OUT/pmc_write $OUT/roofline_traffic.json $OUT/roofline
+python scripts/parse_trace.py $OUT/prof_roofline qbp_cell > $OUT/roofline_kernel_durations.txt; cat $OUT/roofline_kernel_durations.txt
+BQ_SHAPES=0,1,2,3,7,4,5 timeout -k 10 200 python3 scripts/probes/bq_sorted_timing.py 2>/dev/null | grep "^[0-9]" > $OUT/bq_sorted_timing.txt; cat $OUT/bq_sorted_timing.txt | cut -c1-250
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_two_stage -o two_stage -- python3 scripts/two_stage_profile.py > $OUT/two_stage.log 2>&1; echo "rocprof two-stage exit $?"; tail -1 $OUT/two_stage.log
+timeout -k 10 200 python scripts/bev_nms_timing.py > $OUT/bev_nms_timing.json 2>&1; echo "bev_nms_timing exit $?"; tail -3 $OUT/bev_nms_timing.json
+echo done
