@@ -670,21 +670,35 @@ constexpr int kSweepLead = 4;   // steps between the request of a column's first
 // resolves the block by the whole-wave fixed point, publishes how far the ring has been consumed.  No workgroup barrier inside
 // the walk; every wait is on an LDS word that another wave is bound to write (producers fill columns in increasing order, space
 // in the ring is granted in column order, the consumer takes columns in order), so every wave reaches the end.
-constexpr int kStreamMaxBlocks = 1024;      // 65 536 boxes: keptw + cnts + pref + ready = 20 KB
-constexpr int kStreamRing = 8192;           // entries (128 KB, a power of two): four full columns
-constexpr int kStreamAhead = 4;             // blocks whose diagonal / next words wave 0 holds in registers
+constexpr int kStreamMaxBlocks = 1024;      // 65 536 boxes: keptw + cnts + pref + two flag arrays = 24 KB
+constexpr int kStreamRing = 4096;           // list entries in the ring (64 KB, a power of two): two full columns
+constexpr int kStreamWords = 64;            // blocks whose (diagonal, next) word pairs sit in LDS ahead of wave 0 (64 KB)
+constexpr int kStreamWordWaves = 8;         // waves 1..8 stream those words, waves 9..15 the list entries
+constexpr int kStreamMaxAverage = 32;       // entries per column block on average up to which one consuming wave keeps up (measured:
+                                            // 9000 clustered boxes at threshold 0.01 hold 86 per column and run 260 us streaming against 222;
+                                            // at the RPN's 0.8 the lists of uniform and clustered boxes alike hold ~20 entries IN TOTAL)
 
 __device__ __forceinline__ int lds_load_i32(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__device__ void sweep_stream(int n, int cb, const int *__restrict__ counts, const NmsEntry *__restrict__ lists,
+// Wave 0 issues NO global load: a first version prefetched its diagonal / next words into registers eight blocks ahead, and the
+// compiler's wait-count insertion (loops with data-dependent trip counts around the uses) put an `s_waitcnt vmcnt(0)` into every
+// step -- each block then paid a full memory round trip behind its own `keep[]` store (0.39 us per block, empty lists or not).
+// Waves 1..8 stream those word pairs into LDS instead, waves 9..15 the list entries.
+__device__ __forceinline__ void sweep_stream(int n, int cb, const int *__restrict__ counts, const NmsEntry *__restrict__ lists,
                              const unsigned long long *__restrict__ diagt, const unsigned long long *__restrict__ nextw,
                              int *__restrict__ keep, unsigned char *smem_raw, int *kept_total, int *consumed_pref, int *scan_ws)
 {
-    unsigned long long *keptw = reinterpret_cast<unsigned long long *>(smem_raw);          // cb   kept bits per block
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    // the 16-byte arrays first (smem_raw is 16-byte aligned): no integer arithmetic on the pointers -- a round trip through
+    // uintptr_t made the compiler forget that these are LDS addresses and read them with FLAT loads (hundreds of cycles each)
+    ull2 *words = reinterpret_cast<ull2 *>(smem_raw);                                        // kStreamWords * 64
+    NmsEntry *ring = reinterpret_cast<NmsEntry *>(words + kStreamWords * 64);                // kStreamRing
+    unsigned long long *keptw = reinterpret_cast<unsigned long long *>(ring + kStreamRing);  // cb   kept bits per block
     int *cnts = reinterpret_cast<int *>(keptw + cb);                                         // cb   entries filed under the block
     int *pref = cnts + cb;                                                                   // cb + 1   entries before the block
     int *ready = pref + cb + 1;                                                              // cb   the block's entries are in the ring
-    NmsEntry *ring = reinterpret_cast<NmsEntry *>((reinterpret_cast<uintptr_t>(ready + cb) + 15) & ~static_cast<uintptr_t>(15));
+    int *wready = ready + cb;                                                                // cb   the block's word pairs are in LDS
+    int *consumed_blk = scan_ws + 30;                                                        // blocks wave 0 is done with
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     // exclusive prefix of the counts (cb <= 1024 = one value per thread)
@@ -692,13 +706,34 @@ __device__ void sweep_stream(int n, int cb, const int *__restrict__ counts, cons
         const int c = t < cb ? counts[t] : 0;
         int total = 0;
         const int ex = block_exclusive_scan(c, scan_ws, &total);
-        if (t < cb) { cnts[t] = c; pref[t] = ex; ready[t] = 0; keptw[t] = 0ull; }
-        if (t == 0) { pref[cb] = total; *kept_total = 0; *consumed_pref = 0; }
+        if (t < cb) { cnts[t] = c; pref[t] = ex; ready[t] = 0; wready[t] = 0; keptw[t] = 0ull; }
+        if (t == 0) { pref[cb] = total; *kept_total = 0; *consumed_pref = 0; *consumed_blk = 0; }
     }
     __syncthreads();
-    if (wave > 0) {
-        // ---------------- producers: columns wave-1, wave-1+15, ... in increasing order ----------------
-        for (int col = wave - 1; col < cb; col += kSweepThreads / 64 - 1) {
+    if (wave >= 1 && wave <= kStreamWordWaves) {
+        // ---------------- the (diagonal, next) words of every block: a wave moves four blocks per memory round trip, eight waves
+        // take turns (one wave alone fed wave 0 a block per 0.37 us -- exactly what the walk then took) ----------------
+        for (int b0 = 4 * (wave - 1); b0 < cb; b0 += 4 * kStreamWordWaves) {
+            while (b0 + 4 - lds_load_i32(consumed_blk) > kStreamWords) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+            unsigned long long d[4], x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int blk = b0 + j, i = blk * 64 + lane;
+                d[j] = (blk < cb && i < n) ? diagt[i] : 0ull;
+                x[j] = (blk >= 1 && blk < cb) ? nextw[i - 64] : 0ull;   // boxes of block blk-1 all exist
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (b0 + j < cb) words[((b0 + j) & (kStreamWords - 1)) * 64 + lane] = ull2{ d[j], x[j] };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < 4 && b0 + lane < cb) __hip_atomic_store(&wready[b0 + lane], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    if (wave > kStreamWordWaves) {
+        // ---------------- list entries: the remaining waves, a column each, in increasing order ----------------
+        for (int col = wave - 1 - kStreamWordWaves; col < cb; col += kSweepThreads / 64 - 1 - kStreamWordWaves) {
             const int cnt = cnts[col];
             if (cnt == 0) continue;   // the consumer does not wait for an empty column
             const int base = pref[col];
@@ -722,34 +757,53 @@ __device__ void sweep_stream(int n, int cb, const int *__restrict__ counts, cons
         }
         return;
     }
-    // ---------------- consumer: wave 0 ----------------
+    // ---------------- consumer: wave 0.  Per block: word pair (LDS) -> [ring entries -> kept bits of their rows] -> ballots ----------------
     __builtin_amdgcn_s_setprio(3);
-    unsigned long long dg[kStreamAhead], nx[kStreamAhead];   // diagonal word of box blk*64+lane, next word of box (blk-1)*64+lane
-    auto fetch = [&](int blk, unsigned long long &d, unsigned long long &x) {
-        const int i = blk * 64 + lane;
-        d = (blk < cb && i < n) ? diagt[i] : 0ull;
-        x = (blk >= 1 && blk < cb) ? nextw[i - 64] : 0ull;   // boxes of block blk-1 all exist
-    };
-#pragma unroll
-    for (int j = 0; j < kStreamAhead; ++j) fetch(j, dg[j], nx[j]);
     int total_kept = 0;
-    auto step = [&](int blk, unsigned long long &d, unsigned long long &x) {
+    unsigned long long kb_prev = 0ull;   // the kept bits of the block before (wave-uniform)
+    // One wave runs ~100 instructions per block back to back, so every LDS round trip inside the block's dependent chain shows
+    // (0.37 us per block with four of them).  What the NEXT block needs from LDS and depends on no decision -- its flag, word
+    // pair, entry count and ring offset -- is therefore requested at the top of the current block and has arrived when it is
+    // used.  The flag is read BEFORE the words (the LDS keeps a wave's order, the producer wrote the words before the flag):
+    // a set flag vouches for the words read after it; a clear one means wait and read again.
+    // (a taken branch costs a lone wave more than a handful of instructions: the walk is written branch-lean -- the peek past the
+    // last block re-reads the last block, uniform values are stored by every lane, the keep[] store is a range-checked buffer
+    // store whose unkept lanes aim past the end)
+    auto peek = [&](int blk, int &flag, ull2 &w, int &cnt, int &base) {
+        const int bk = min(blk, cb - 1);
+        flag = lds_load_i32(&wready[bk]);
+        w = words[(bk & (kStreamWords - 1)) * 64 + lane];
+        cnt = cnts[bk];
+        base = pref[bk];
+    };
+    const __amdgpu_buffer_rsrc_t rkeep = __builtin_amdgcn_make_buffer_rsrc(keep, 0, n * 4, 0x00020000);
+    int flag_n, cnt_n, base_n;
+    ull2 w_n;
+    peek(0, flag_n, w_n, cnt_n, base_n);
+    for (int blk = 0; blk < cb; ++blk) {
+        int flag = flag_n;
+        ull2 w = w_n;
+        const int cnt = cnt_n, base = base_n;
+        if (flag == 0) {   // uniform: the producers are behind (start of the kernel)
+            while (lds_load_i32(&wready[blk]) == 0) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            w = words[(blk & (kStreamWords - 1)) * 64 + lane];
+        }
+        peek(blk + 1, flag_n, w_n, cnt_n, base_n);
         const int lim = min(64, n - blk * 64);
         const unsigned long long valid = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
         // (1) the words of the column's entries whose row was kept
         unsigned long long acc = 0ull;
-        const int cnt = cnts[blk];
         if (cnt > 0) {
             while (lds_load_i32(&ready[blk]) == 0) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
-            const int base = pref[blk];
             for (int k = lane; k < cnt; k += 64) {
                 const NmsEntry e = ring[(base + k) & (kStreamRing - 1)];
                 if ((keptw[e.row >> 6] >> (e.row & 63)) & 1ull) acc |= e.word;
             }
         }
         // (2) the next words of the boxes kept in block blk-1
-        if (blk > 0 && ((keptw[blk - 1] >> lane) & 1ull)) acc |= x;
+        if ((kb_prev >> lane) & 1ull) acc |= w.y;
         // OR over the wave: few lanes hold anything
         unsigned long long remv = 0ull;
         for (unsigned long long m = __ballot(acc != 0ull); m; m &= m - 1ull) {
@@ -759,29 +813,23 @@ __device__ void sweep_stream(int n, int cb, const int *__restrict__ counts, cons
             remv |= (static_cast<unsigned long long>(hi) << 32) | lo;
         }
         // (3) resolve: kept[l] = alive[l] and no kept killer (fixed point over the wave, as in the barrier form)
-        const unsigned long long killers = lane < lim ? d : 0ull;
+        const unsigned long long killers = lane < lim ? w.x : 0ull;
         const unsigned long long alive = ~remv & valid;
-        unsigned long long kb = alive;
-        for (;;) {
-            const unsigned long long next = alive & ~__ballot((killers & kb) != 0ull);
-            if (next == kb) break;
-            kb = next;
+        // two rounds unconditionally (no suppression inside the block -- the usual case -- is confirmed by the second), then until stable
+        unsigned long long kb = alive & ~__ballot((killers & alive) != 0ull);
+        unsigned long long nextk = alive & ~__ballot((killers & kb) != 0ull);
+        while (nextk != kb) {
+            kb = nextk;
+            nextk = alive & ~__ballot((killers & kb) != 0ull);
         }
-        if ((kb >> lane) & 1ull) keep[total_kept + __builtin_popcountll(kb & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+        __builtin_amdgcn_raw_buffer_store_b32(static_cast<unsigned>(blk * 64 + lane), rkeep,
+                                              ((kb >> lane) & 1ull) ? (total_kept + mask_prefix(kb)) * 4 : -16, 0, 0);
         total_kept += __builtin_popcountll(kb);
-        if (lane == 0) {
-            keptw[blk] = kb;
-            __hip_atomic_store(consumed_pref, pref[blk + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // the ring up to here is free
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // keptw[blk] is visible to this wave's next reads (same wave: in order anyway)
-        fetch(blk + kStreamAhead, d, x);
-    };
-    static_assert(kStreamAhead == 4, "four register sets rotate below");
-    for (int base = 0; base < cb; base += 4) {
-        step(base, dg[0], nx[0]);
-        if (base + 1 < cb) step(base + 1, dg[1], nx[1]);
-        if (base + 2 < cb) step(base + 2, dg[2], nx[2]);
-        if (base + 3 < cb) step(base + 3, dg[3], nx[3]);
+        kb_prev = kb;
+        // every lane stores the same values: no exec juggling, no branch
+        keptw[blk] = kb;   // read by this wave's later steps: the LDS keeps a wave's accesses in order
+        __hip_atomic_store(consumed_pref, base + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // the ring up to here is free
+        __hip_atomic_store(consumed_blk, blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (lane == 0) *kept_total = total_kept;
 }
@@ -811,11 +859,19 @@ __global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(int n, int chu
     const int t = threadIdx.x;
     // ---- the streaming form (round 4): no barrier per column block.  Taken when no column's list overflowed and the per-block
     // arrays plus the entry ring fit in LDS (cb <= kStreamMaxBlocks = 65 536 boxes); else the barrier form below. ----
-    if (t == 0) any_overflow = 0;
+    if (t == 0) { any_overflow = 0; scan_ws[31] = 0; }
     __syncthreads();
     if (cb <= kStreamMaxBlocks) {
-        for (int w = t; w < cb; w += kSweepThreads)
-            if (counts[w] > kNmsListCap) any_overflow = 1;
+        // not taken either when the lists are long on average: one wave then tests more entries per block than the fifteen
+        // gatherers of the barrier form do in a step
+        int mine = 0;
+        for (int w = t; w < cb; w += kSweepThreads) {
+            const int c = counts[w];
+            if (c > kNmsListCap) any_overflow = 1;
+            mine += c;
+        }
+        if (mine > kStreamMaxAverage * cb / 4) any_overflow = 1;            // a thread's share alone says "long" (cheap early out)
+        else if (mine > 0 && atomicAdd(&scan_ws[31], mine) + mine > kStreamMaxAverage * cb) any_overflow = 1;
     }
     __syncthreads();
     if (cb <= kStreamMaxBlocks && !any_overflow) {
@@ -1001,7 +1057,8 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
     size_t lds = sizeof(unsigned long long) * (2 * static_cast<size_t>(cb) + 2 * 64 * static_cast<size_t>(chunk_blocks)) + sizeof(int) * static_cast<size_t>(cb);
     if (cb > 8192 || lds > 160 * 1024 - 256) return HF_EINVAL;   // n <= 524 288 boxes (pre_nms_size is 9000)
     if (cb <= kStreamMaxBlocks)   // the streaming sweep: per-block arrays + the ring of list entries
-        lds = std::max(lds, sizeof(unsigned long long) * cb + sizeof(int) * (3 * static_cast<size_t>(cb) + 1) + 16 + sizeof(NmsEntry) * kStreamRing);
+        lds = std::max(lds, sizeof(unsigned long long) * cb + sizeof(int) * (4 * static_cast<size_t>(cb) + 1) + 16 + 16 * 64 * static_cast<size_t>(kStreamWords) +
+                                sizeof(NmsEntry) * kStreamRing);
     hipStream_t st = as_stream(stream);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     const size_t ws_stride = nms_ws_bytes(n);

@@ -39,30 +39,33 @@ __global__ __launch_bounds__(kAdamThreads) void adam_multi_kernel(const AdamEntr
     const float sq2 = sqrtf(bc2);
     const float a = mode == 0 ? lr * sq2 / bc1 : lr / bc1;
     const float inv_sq2 = 1.0f / sq2;
-    float *p = e.p + o0;
-    const float *g = e.g + o0;
-    float *m = e.m + o0;
-    float *v = e.v + o0;
-    auto upd = [&](float &pp, float gg, float &mm, float &vv) {
+    // the four pointers come out of a table in memory: tell the compiler they are GLOBAL addresses (else it emits FLAT accesses)
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat *p = (gfloat *)(e.p + o0);
+    const gfloat *g = (const gfloat *)(e.g + o0);
+    gfloat *m = (gfloat *)(e.m + o0);
+    gfloat *v = (gfloat *)(e.v + o0);
+    auto upd = [&](auto &pp, float gg, auto &mm, auto &vv) {
         gg *= grad_scale;
         mm = b1 * mm + (1.0f - b1) * gg;
         vv = b2 * vv + (1.0f - b2) * gg * gg;
         const float d = mode == 0 ? sqrtf(vv) + eps : sqrtf(vv) * inv_sq2 + eps;
         pp -= a * mm / d;
     };
-    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                      reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const bool al = ((reinterpret_cast<uintptr_t>(e.p + o0) | reinterpret_cast<uintptr_t>(e.g + o0) | reinterpret_cast<uintptr_t>(e.m + o0) |
+                      reinterpret_cast<uintptr_t>(e.v + o0)) & 15) == 0;
     if (al) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const long long n4 = n >> 2;
         for (long long i = threadIdx.x; i < n4; i += kAdamThreads) {
-            f4 pv = reinterpret_cast<f4 *>(p)[i], mv = reinterpret_cast<f4 *>(m)[i], vv = reinterpret_cast<f4 *>(v)[i];
-            const f4 gv = reinterpret_cast<const f4 *>(g)[i];
+            typedef __attribute__((address_space(1))) f4 gf4;
+            f4 pv = ((gf4 *)p)[i], mv = ((gf4 *)m)[i], vv = ((gf4 *)v)[i];
+            const f4 gv = ((const gf4 *)g)[i];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { float a_ = pv[k], m_ = mv[k], v_ = vv[k]; upd(a_, gv[k], m_, v_); pv[k] = a_; mv[k] = m_; vv[k] = v_; }
-            reinterpret_cast<f4 *>(p)[i] = pv;
-            reinterpret_cast<f4 *>(m)[i] = mv;
-            reinterpret_cast<f4 *>(v)[i] = vv;
+            ((gf4 *)p)[i] = pv;
+            ((gf4 *)m)[i] = mv;
+            ((gf4 *)v)[i] = vv;
         }
         for (long long i = (n4 << 2) + threadIdx.x; i < n; i += kAdamThreads) upd(p[i], g[i], m[i], v[i]);
     } else {
