@@ -529,7 +529,8 @@ def parse_args(argv=None):
                     help="hf: optim.MultiTensorAdam (every parameter tensor in one launch, csrc/optim.hip, torch.optim.Adam's "
                          "arithmetic); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--x-branch-stream", choices=("auto", "on", "off"), default="auto",
-                    help="the X-transformation branch of every X-Conv on a side HIP stream (pointcnn.CONCURRENT_X_BRANCH); auto = on")
+                    help="the X-transformation branch of every X-Conv on a side HIP stream (pointcnn.CONCURRENT_X_BRANCH); auto = on, except "
+                         "for enqueued steps under DistributedDataParallel")
     ap.add_argument("--gemm-tuning", default="off",
                     help="off (default): the library's own heuristic; auto: load heterofusionrcnn_amd/tuned_gemms.csv if present "
                          "(library-GEMM selections per shape, PyTorch TunableOp); tune:<file>: time the candidates of every shape of "
@@ -725,7 +726,9 @@ def main():
         prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth, group=group)
         lr = dp.scaled_lr(1e-3, world)                                   # optimizer_builder.py:105
         from heterofusionrcnn_amd import pointcnn as pointcnn_mod
-        pointcnn_mod.CONCURRENT_X_BRANCH = args.x_branch_stream != "off"     # measured: -1.6 ms at 1 frame (replayed), -1.5 ms at 8 (enqueued)
+        # measured: -1.6 ms at 1 frame (replayed), -1.5 ms at 8 (enqueued).  Not under DistributedDataParallel (several ranks, enqueued steps):
+        # its bucket hooks copy gradients as they appear, on whatever stream the producing node ran
+        pointcnn_mod.CONCURRENT_X_BRANCH = args.x_branch_stream == "on" or (args.x_branch_stream == "auto" and (use_graph or world == 1))
         from heterofusionrcnn_amd.optim import MultiTensorAdam
         make_opt = ((lambda ps, capturable: MultiTensorAdam(ps, lr=lr, tf_epsilon=False)) if args.optimizer == "hf" else
                     (lambda ps, capturable: torch.optim.Adam(ps, lr=lr, fused=True, capturable=capturable)))

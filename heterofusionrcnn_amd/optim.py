@@ -48,11 +48,12 @@ class MultiTensorAdam:
         self.step_count = torch.zeros((), dtype=torch.float32, device=dev)     # on the device: a captured step advances it
         self.chunk = _lib.lib().hf_adam_chunk()
         n = len(self.params)
-        self._host_table = torch.empty(n * ctypes.sizeof(_Entry), dtype=torch.uint8).pin_memory()
-        self._dev_table = torch.empty(n * ctypes.sizeof(_Entry), dtype=torch.uint8, device=dev)
-        self._host_map = torch.empty((sum((p.numel() + self.chunk - 1) // self.chunk for p in self.params), 2), dtype=torch.int32).pin_memory()
-        self._dev_map = torch.empty_like(self._host_map, device=dev)
-        self._key, self._chunks = None, 0
+        self._table_bytes = n * ctypes.sizeof(_Entry)
+        self._map_rows = sum((p.numel() + self.chunk - 1) // self.chunk for p in self.params)
+        self._host_table = self._host_map = None       # pinned staging of the CURRENT table (kept alive: a captured upload re-reads it)
+        self._dev_table = torch.empty(self._table_bytes, dtype=torch.uint8, device=dev)
+        self._dev_map = torch.empty((self._map_rows, 2), dtype=torch.int32, device=dev)
+        self._key, self._chunks, self._captured_staging = None, 0, []
         self.total_elements = total
 
     # the framework optimizers' surface that callers here use
@@ -68,6 +69,11 @@ class MultiTensorAdam:
         key = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self.params)
         if key == self._key:
             return
+        # FRESH pinned staging buffers per rewrite: the upload below is asynchronous and the host may be several steps ahead of the
+        # device -- rewriting one shared buffer would hand an earlier, not yet executed upload the later step's pointers.  (The
+        # caching host allocator recycles a pinned block only after the stream has passed the copy that read it.)
+        self._host_table = torch.empty(self._table_bytes, dtype=torch.uint8).pin_memory()
+        self._host_map = torch.empty((self._map_rows, 2), dtype=torch.int32).pin_memory()
         entries = (_Entry * len(self.params)).from_buffer(self._host_table.numpy())
         rows, live = [], 0
         for i, p in enumerate(self.params):
@@ -86,6 +92,8 @@ class MultiTensorAdam:
         # same bytes at every replay, 12 KB)
         self._dev_table.copy_(self._host_table, non_blocking=True)
         self._dev_map.copy_(self._host_map, non_blocking=True)
+        if torch.cuda.is_current_stream_capturing():
+            self._captured_staging.append((self._host_table, self._host_map))      # the graph's upload nodes read these at every replay
         self._key = key
 
     @torch.no_grad()
