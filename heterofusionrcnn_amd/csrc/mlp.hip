@@ -28,6 +28,8 @@ struct BnGeom {
     long long rows_per_block;
 };
 
+constexpr int kBnRowsPerThread = 8;
+
 static BnGeom bn_geom(long long rows, int c)
 {
     BnGeom g;
@@ -35,7 +37,10 @@ static BnGeom bn_geom(long long rows, int c)
     g.cv = c / g.vec;
     g.rpb = g.cv >= 256 ? 1 : 256 / g.cv;
     g.threads = g.cv * g.rpb;
-    long long nblk = (rows + g.rpb - 1) / g.rpb;
+    // >= kBnRowsPerThread rows per thread before another block is opened: a 16384 x 64 tensor is 128 blocks (one partial line each
+    // per channel), not 1024 one-row-per-thread blocks whose partials (2 x 64 floats at an 8 KB stride) outweigh the tensor
+    const long long per_block = static_cast<long long>(g.rpb) * HF_DIAG_INT("HF_BN_ROWS_PER_THREAD", kBnRowsPerThread);
+    long long nblk = (rows + per_block - 1) / per_block;
     if (nblk > kBnMaxBlocks) nblk = kBnMaxBlocks;
     if (nblk < 1) nblk = 1;
     long long rpbk = (rows + nblk - 1) / nblk;
@@ -110,25 +115,23 @@ __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long lon
     }
 }
 
-// one 256-thread workgroup per channel: fp64 tree reduction of that channel's two partial rows
+// one WAVE per channel (four channels per 256-thread workgroup): fp64 sums of that channel's two partial rows, combined across the
+// lanes without LDS or barriers.  Valid in every lane on return.
+constexpr int kBnFinalizeChannels = 4;
+__device__ __forceinline__ int bn_finalize_channel() { return blockIdx.x * kBnFinalizeChannels + (threadIdx.x >> 6); }
+
 __device__ __forceinline__ void bn_reduce_channel(const float *__restrict__ partial, int c, int nblk, int ch, double &s,
                                                   double &q)
 {
-    __shared__ double red[2][256];
-    const int t = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     double a = 0.0, b = 0.0;
     const float *p0 = partial + static_cast<size_t>(ch) * kBnMaxBlocks;
     const float *p1 = partial + static_cast<size_t>(c + ch) * kBnMaxBlocks;
-    for (int i = t; i < nblk; i += 256) { a += static_cast<double>(p0[i]); b += static_cast<double>(p1[i]); }
-    red[0][t] = a;
-    red[1][t] = b;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
-        __syncthreads();
-    }
-    s = red[0][0];
-    q = red[1][0];
+    for (int i = lane; i < nblk; i += 64) { a += static_cast<double>(p0[i]); b += static_cast<double>(p1[i]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    s = a;
+    q = b;
 }
 
 // batch statistics, running statistics: running = (1-m)*running + m*batch with the BIASED batch variance -- what
@@ -141,10 +144,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, 
                                                                 float *__restrict__ save_mean,
                                                                 float *__restrict__ save_invstd)
 {
-    const int ch = blockIdx.x;
+    const int ch = bn_finalize_channel();
+    if (ch >= c) return;
     double s, q;
     bn_reduce_channel(partial, c, nblk, ch, s, q);
-    if (threadIdx.x != 0) return;
+    if ((threadIdx.x & 63) != 0) return;
     const double mean = s / static_cast<double>(rows);
     double var = q / static_cast<double>(rows) - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -236,10 +240,11 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int c, int nblk, const float *__restrict__ partial,
                                                               float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
-    const int ch = blockIdx.x;
+    const int ch = bn_finalize_channel();
+    if (ch >= c) return;
     double s1, s2;
     bn_reduce_channel(partial, c, nblk, ch, s1, s2);
-    if (threadIdx.x != 0) return;
+    if ((threadIdx.x & 63) != 0) return;
     dbeta[ch] = static_cast<float>(s1);
     dgamma[ch] = static_cast<float>(s2);
 }
@@ -301,10 +306,228 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
 __global__ __launch_bounds__(256) void bn_colsum_finalize_kernel(int c, int nblk, const float *__restrict__ partial,
                                                                  float *__restrict__ colsum)
 {
-    const int ch = blockIdx.x;
+    const int ch = bn_finalize_channel();
+    if (ch >= c) return;
     double s, q;
     bn_reduce_channel(partial, c, nblk, ch, s, q);
-    if (threadIdx.x == 0) colsum[ch] = static_cast<float>(s);
+    if ((threadIdx.x & 63) == 0) colsum[ch] = static_cast<float>(s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Short tensors (rows <= kBnSmallMaxRows, C % 4 == 0): ONE launch per direction instead of three.  At one frame per GPU the
+// step holds ~45 such BatchNorms (the K*K-channel X-transformation layers and everything below 4096 points): three launches of
+// 5-9 us each for a tensor that fits a few CUs' registers.  A workgroup owns `cvw` channel vectors (<= 128 bytes of a row) and
+// ALL rows: every thread keeps its <= 8 rows in registers, the sums meet in LDS, the same registers are normalised and stored.
+// No inter-workgroup traffic, no partials in memory.
+// ------------------------------------------------------------------------------------------
+// the single-launch kernels run ~4 waves per CU on a handful of CUs, so the activation's instruction count shows: exp(x) - 1 on
+// the hardware exponential (TensorFlow's own formula for tf.nn.elu, relu_op_functor.h; the lifting kernels of gemm.hip use it
+// too) and its gradient from the OUTPUT, (y + 1) dy for y <= 0, as TensorFlow's EluGrad does -- one v_exp_f32 per element
+__device__ __forceinline__ float elu_hw(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+__device__ __forceinline__ float elu_slope_from_output(float y) { return y > 0.0f ? 1.0f : y + 1.0f; }
+
+constexpr int kBnSmallRowsPerThread = 8;
+constexpr int kBnSmallMaxRows = 4096;
+
+struct BnSmallGeom { int cvw, threads, rpb, nwg; };
+
+static bool bn_small_geom(long long rows, int c, BnSmallGeom &g)
+{
+    if (c % 4 != 0 || rows > HF_DIAG_INT("HF_BN_SMALL_ROWS", kBnSmallMaxRows)) return false;
+    const int cv = c / 4;
+    int cvw = HF_DIAG_INT("HF_BN_SMALL_CVW", 8);
+    // measured (scripts/probes/bn_small_timing.py, profiles/r04_bn_small_timing.txt): 256-thread workgroups win up to 1024 rows, 512 beyond;
+    // 1024-thread workgroups (a whole CU's registers in the backward kernel) lose to both, and at 4096 rows x > 128 channels the
+    // line re-fetch of the narrow channel slices (every workgroup touches every row's 128-byte line) costs more than two launches
+    if (rows > 2048 && c > 128) return false;
+    const int tmax = HF_DIAG_INT("HF_BN_SMALL_THREADS", rows <= 1024 ? 256 : 512);
+    while (cvw > 1 && (cvw > cv || static_cast<long long>(cvw) * rows > tmax * kBnSmallRowsPerThread)) cvw >>= 1;
+    long long want = rows < tmax / cvw ? rows : tmax / cvw;      // row lanes
+    int threads = static_cast<int>((want * cvw + 63) / 64 * 64);
+    if (threads > tmax) threads = tmax;
+    g.cvw = cvw;
+    g.threads = threads;
+    g.rpb = threads / cvw;
+    g.nwg = (cv + cvw - 1) / cvw;
+    return static_cast<long long>(g.rpb) * kBnSmallRowsPerThread >= rows;
+}
+
+// sums of v[0..7] over the lanes that share a channel vector (stride cvw inside a wave), over the waves through `part`, in fp64;
+// on return the lanes t = cl*8 + j of wave 0 (t < cvw*8) hold the total of component j of channel vector cl
+__device__ __forceinline__ double bn_small_reduce(float (&v)[8], int cvw, float (*part)[8][8])
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    for (int off = cvw; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += __shfl_xor(v[j], off);
+    }
+    if (lane < cvw) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[wave][lane][j] = v[j];
+    }
+    __syncthreads();
+    double acc = 0.0;
+    if (t < cvw * 8) {
+        for (int w = 0; w < nw; ++w) acc += static_cast<double>(part[w][t >> 3][t & 7]);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(1024) void bn_small_fwd_kernel(int rows, int c, int cvw, int rpb, const float *__restrict__ x,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           float eps, float momentum, float *__restrict__ running_mean,
+                                                           float *__restrict__ running_var, int relu, float *__restrict__ y,
+                                                           long long ldy, float *__restrict__ save_mean,
+                                                           float *__restrict__ save_invstd)
+{
+    __shared__ float part[16][8][8];
+    __shared__ float coef[8][12];
+    typedef VecT<4>::type f4;
+    const int t = threadIdx.x;
+    const int cl = t % cvw, rsub = t / cvw;
+    const int cv = c >> 2;
+    const int cvec = blockIdx.x * cvw + cl;
+    const bool chan_ok = cvec < cv;
+    const int cvec_c = chan_ok ? cvec : cv - 1;
+    f4 xv[kBnSmallRowsPerThread];
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kBnSmallRowsPerThread; ++i) {
+        const int r = rsub + i * rpb;
+        const bool ok = chan_ok && r < rows;
+        const f4 v = ldv<4>(x + static_cast<long long>(r < rows ? r : rows - 1) * c + cvec_c * 4);   // always a valid address
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float f = v[j];
+            if (relu & kBnEluIn) f = elu_hw(f);
+            f = ok ? f : 0.f;
+            xv[i][j] = f;
+            acc[j] += f;
+            acc[4 + j] += f * f;
+        }
+    }
+    const double tot = bn_small_reduce(acc, cvw, part);
+    if (t < cvw * 8) {
+        const double other = __shfl_xor(tot, 4);      // lanes j < 4 hold sum x and fetch sum x^2 from lane j + 4
+        const int j = t & 7, ch = (blockIdx.x * cvw + (t >> 3)) * 4 + (j & 3);
+        if (j < 4 && ch < c) {
+            const double mean = tot / static_cast<double>(rows);
+            double var = other / static_cast<double>(rows) - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float is = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+            save_mean[ch] = static_cast<float>(mean);
+            save_invstd[ch] = is;
+            if (running_mean) running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * static_cast<float>(mean);
+            if (running_var) running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * static_cast<float>(var);
+            coef[t >> 3][j] = gamma[ch] * is;
+            coef[t >> 3][4 + j] = static_cast<float>(mean);
+            coef[t >> 3][8 + j] = beta[ch];
+        }
+    }
+    __syncthreads();
+    if (!chan_ok) return;
+    float a[4], mu[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = coef[cl][j]; mu[j] = coef[cl][4 + j]; b[j] = coef[cl][8 + j]; }
+#pragma unroll
+    for (int i = 0; i < kBnSmallRowsPerThread; ++i) {
+        const int r = rsub + i * rpb;
+        if (r < rows) {
+            f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float h = a[j] * (xv[i][j] - mu[j]) + b[j];
+                if (relu & kBnRelu) h = fmaxf(h, 0.0f);
+                o[j] = h;
+            }
+            stv<4>(y + static_cast<long long>(r) * ldy + cvec * 4, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_small_bwd_kernel(int rows, int c, int cvw, int rpb, const float *__restrict__ x,
+                                                           const float *__restrict__ dy, long long lddy,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                           int relu, float *__restrict__ dx, float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta, float *__restrict__ dx_colsum)
+{
+    __shared__ float part[16][8][8];
+    __shared__ float tot_s[8][8];
+    typedef VecT<4>::type f4;
+    const int t = threadIdx.x;
+    const int cl = t % cvw, rsub = t / cvw;
+    const int cv = c >> 2;
+    const int cvec = blockIdx.x * cvw + cl;
+    const bool chan_ok = cvec < cv;
+    const int cvec_c = chan_ok ? cvec : cv - 1;
+    float a[4], b[4], mu[4], is[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = cvec_c * 4 + j;
+        mu[j] = mean[ch]; is[j] = invstd[ch];
+        a[j] = gamma[ch] * is[j];
+        b[j] = beta[ch];
+    }
+    f4 xv[kBnSmallRowsPerThread], gv[kBnSmallRowsPerThread];    // x behind the ELU (if any); dh (dy behind the ReLU mask)
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kBnSmallRowsPerThread; ++i) {
+        const int r = rsub + i * rpb;
+        const bool ok = chan_ok && r < rows;
+        const long long rc = r < rows ? r : rows - 1;
+        const f4 xr = ldv<4>(x + rc * c + cvec_c * 4);
+        const f4 g = ldv<4>(dy + rc * lddy + cvec_c * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xe = (relu & kBnEluIn) ? elu_hw(xr[j]) : xr[j];
+            xv[i][j] = xe;
+            float dh = ok ? g[j] : 0.f;
+            if ((relu & kBnRelu) && !(a[j] * (xe - mu[j]) + b[j] > 0.0f)) dh = 0.0f;
+            gv[i][j] = dh;
+            acc[j] += dh;
+            acc[4 + j] += dh * ((xe - mu[j]) * is[j]);
+        }
+    }
+    const double tot = bn_small_reduce(acc, cvw, part);
+    if (t < cvw * 8) {
+        const int j = t & 7, ch = (blockIdx.x * cvw + (t >> 3)) * 4 + (j & 3);
+        const float f = static_cast<float>(tot);
+        tot_s[t >> 3][j] = f;
+        if (ch < c) { if (j < 4) dbeta[ch] = f; else dgamma[ch] = f; }
+    }
+    __syncthreads();
+    const float inv_r = 1.0f / static_cast<float>(rows);
+    float c1[4], c2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c1[j] = tot_s[cl][j] * inv_r; c2[j] = tot_s[cl][4 + j] * inv_r; acc[j] = 0.f; acc[4 + j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < kBnSmallRowsPerThread; ++i) {
+        const int r = rsub + i * rpb;
+        const bool ok = chan_ok && r < rows;
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xe = xv[i][j];
+            const float xhat = (xe - mu[j]) * is[j];
+            float d = a[j] * (gv[i][j] - c1[j] - xhat * c2[j]);
+            if (relu & kBnEluIn) d = d * elu_slope_from_output(xe);
+            o[j] = d;
+            acc[j] += ok ? d : 0.f;
+        }
+        if (ok) stv<4>(dx + static_cast<long long>(r) * c + cvec * 4, o);
+    }
+    if (dx_colsum) {   // column sums of dx = the bias gradient of the Linear that produced x (uniform branch)
+        const double cs = bn_small_reduce(acc, cvw, part);      // its barrier also orders the reuse of `part`
+        if (t < cvw * 8) {
+            const int j = t & 7, ch = (blockIdx.x * cvw + (t >> 3)) * 4 + j;
+            if (j < 4 && ch < c) dx_colsum[ch] = static_cast<float>(cs);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -456,13 +679,13 @@ __global__ void bn_pool_bwd_dx_kernel(long long rows, int k, int c, int cv, int 
 void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *partial, float eps, float momentum,
                               float *running_mean, float *running_var, float *save_mean, float *save_invstd, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, nblk, partial, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, nblk, partial, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd);
 }
 
 void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma, float *dbeta, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, nblk, partial, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, nblk, partial, dgamma, dbeta);
 }
 
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
@@ -490,6 +713,12 @@ HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const 
     BnGeom g = bn_geom(rows, c);
     if (g.vec == 4 && !(aligned16(x) && aligned16(y) && ld_ok4(ldy))) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
+    BnSmallGeom sg;
+    if (bn_small_geom(rows, c, sg)) {
+        hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(sg.nwg), dim3(sg.threads), 0, st, static_cast<int>(rows), c, sg.cvw, sg.rpb, x,
+                           gamma, beta, eps, momentum, running_mean, running_var, relu, y, ldy, save_mean, save_invstd);
+        return launch_status();
+    }
     float *partial = static_cast<float *>(workspace);
     const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
     if (g.vec == 4)
@@ -498,7 +727,7 @@ HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const 
     else
         hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
                            g.rows_per_block, x, partial, (relu & kBnEluIn) ? 1 : 0);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd);
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
@@ -567,6 +796,12 @@ HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float 
     BnGeom g = bn_geom(rows, c);
     if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx) && ld_ok4(lddy))) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
+    BnSmallGeom sg;
+    if (bn_small_geom(rows, c, sg)) {
+        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(sg.nwg), dim3(sg.threads), 0, st, static_cast<int>(rows), c, sg.cvw, sg.rpb, x, dy,
+                           lddy, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, dx_colsum);
+        return launch_status();
+    }
     float *partial = static_cast<float *>(workspace);
     const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
     if (g.vec == 4)
@@ -575,7 +810,7 @@ HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float 
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
                            g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, partial, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
     float *cpart = dx_colsum ? partial : nullptr;  // the reduce partials were consumed by the finalize kernel above
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
@@ -584,7 +819,7 @@ HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float 
         hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
                            g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy);
     if (dx_colsum)
-        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, cpart, dx_colsum);
+        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, cpart, dx_colsum);
     return launch_status();
 }
 
@@ -640,7 +875,7 @@ HF_API int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z
         else
             hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
                                g.rows_per_block, z, partial, 0);
-        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, st, rows, c, g.nblk, partial, eps, momentum,
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps, momentum,
                            running_mean, running_var, mean, invstd);
     }
     BnGeom gg = bn_geom(groups, c);
@@ -678,7 +913,7 @@ HF_API int hf_bn_relu_maxpool_bwd(long long groups, int k, int c, const float *z
     else
         hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<1>), dim3(gg.nblk), dim3(gg.threads), lds_g, st, groups, k, c, gg.cv,
                            gg.rpb, gg.rows_per_block, z, dpooled, argmax, gamma, beta, save_mean, save_invstd, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, st, c, gg.nblk, partial, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, gg.nblk, partial, dgamma, dbeta);
     float *cpart = dz_colsum ? partial : nullptr;
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_pool_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds_r, st, rows, k, c, g.cv, g.rpb,
@@ -688,6 +923,6 @@ HF_API int hf_bn_relu_maxpool_bwd(long long groups, int k, int c, const float *z
         hipLaunchKernelGGL((bn_pool_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds_r, st, rows, k, c, g.cv, g.rpb,
                            g.rows_per_block, z, dpooled, argmax, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dz,
                            cpart);
-    if (dz_colsum) hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(c), dim3(256), 0, st, c, g.nblk, cpart, dz_colsum);
+    if (dz_colsum) hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, cpart, dz_colsum);
     return launch_status();
 }

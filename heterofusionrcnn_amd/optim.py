@@ -50,11 +50,22 @@ class MultiTensorAdam:
         n = len(self.params)
         self._table_bytes = n * ctypes.sizeof(_Entry)
         self._map_rows = sum((p.numel() + self.chunk - 1) // self.chunk for p in self.params)
-        self._host_table = self._host_map = None       # pinned staging of the CURRENT table (kept alive: a captured upload re-reads it)
+        # pinned staging for the table upload.  The upload is asynchronous and the host may be several steps ahead of the device,
+        # so a rewrite never touches a buffer whose upload may still be pending: eager rewrites rotate through a ring (an event
+        # per slot, waited on before the slot is reused); a capture takes a slot of its own for good (the graph's upload nodes
+        # re-read it at every replay).  All pinned allocations happen outside captures (hipHostMalloc is not capturable).
+        self._ring = [self._new_staging() for _ in range(4)]
+        self._ring_at = 0
+        self._for_captures = [self._new_staging() for _ in range(2)]
+        self._captured_staging = []
         self._dev_table = torch.empty(self._table_bytes, dtype=torch.uint8, device=dev)
         self._dev_map = torch.empty((self._map_rows, 2), dtype=torch.int32, device=dev)
-        self._key, self._chunks, self._captured_staging = None, 0, []
+        self._key, self._chunks = None, 0
         self.total_elements = total
+
+    def _new_staging(self):
+        return [torch.empty(self._table_bytes, dtype=torch.uint8).pin_memory(),
+                torch.empty((self._map_rows, 2), dtype=torch.int32).pin_memory(), None]
 
     # the framework optimizers' surface that callers here use
     def zero_grad(self, set_to_none=True):
@@ -69,12 +80,21 @@ class MultiTensorAdam:
         key = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self.params)
         if key == self._key:
             return
-        # FRESH pinned staging buffers per rewrite: the upload below is asynchronous and the host may be several steps ahead of the
-        # device -- rewriting one shared buffer would hand an earlier, not yet executed upload the later step's pointers.  (The
-        # caching host allocator recycles a pinned block only after the stream has passed the copy that read it.)
-        self._host_table = torch.empty(self._table_bytes, dtype=torch.uint8).pin_memory()
-        self._host_map = torch.empty((self._map_rows, 2), dtype=torch.int32).pin_memory()
-        entries = (_Entry * len(self.params)).from_buffer(self._host_table.numpy())
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            if not self._for_captures:
+                raise RuntimeError("MultiTensorAdam: no pinned staging left for another capture (run one eager step between captures)")
+            slot = self._for_captures.pop()
+            self._captured_staging.append(slot)
+        else:
+            while len(self._for_captures) < 2:
+                self._for_captures.append(self._new_staging())
+            slot = self._ring[self._ring_at]
+            self._ring_at = (self._ring_at + 1) % len(self._ring)
+            if slot[2] is not None:
+                slot[2].synchronize()           # the upload that last read this slot has executed (four rewrites ago: rarely waits)
+        host_table, host_map = slot[0], slot[1]
+        entries = (_Entry * len(self.params)).from_buffer(host_table.numpy())
         rows, live = [], 0
         for i, p in enumerate(self.params):
             g = p.grad
@@ -87,13 +107,14 @@ class MultiTensorAdam:
             live += 1
         self._chunks = len(rows)
         if rows:
-            self._host_map[:len(rows)] = torch.tensor(rows, dtype=torch.int32)
+            host_map[:len(rows)] = torch.tensor(rows, dtype=torch.int32)
         # pinned staging -> device on the current stream (inside a capture this becomes a node of the graph: it re-uploads the
         # same bytes at every replay, 12 KB)
-        self._dev_table.copy_(self._host_table, non_blocking=True)
-        self._dev_map.copy_(self._host_map, non_blocking=True)
-        if torch.cuda.is_current_stream_capturing():
-            self._captured_staging.append((self._host_table, self._host_map))      # the graph's upload nodes read these at every replay
+        self._dev_table.copy_(host_table, non_blocking=True)
+        self._dev_map.copy_(host_map, non_blocking=True)
+        if not capturing:
+            slot[2] = torch.cuda.Event()
+            slot[2].record()
         self._key = key
 
     @torch.no_grad()

@@ -1830,3 +1830,53 @@ def test_dense_chain_inference_form_equals_layer_by_layer(c):
         a = pc.dense_chain(d0, d1, x)
         b = d1(d0(x))
     assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("rows,c,mode", [(64, 64, 1), (4096, 64, 0), (513, 228, 1), (4096, 1024, 2), (3000, 12, 2), (1, 4, 1),
+                                         (4097, 64, 1)])
+def test_bn_short_tensors_strided_and_column_sums(hf, rows, c, mode):
+    """hf_bn_relu_fwd_train_ld / hf_bn_relu_bwd_ld through the C-ABI on tensors of at most 4096 rows (the single-launch kernels
+    of csrc/mlp.hip; 4097 rows = the three-launch form beside them): output rows inside a wider buffer, gradient rows inside a
+    wider buffer, the column sums of dx requested; against fp64 torch.  mode: 0 = BN, 1 = BN + ReLU, 2 = BN of elu(x)"""
+    from heterofusionrcnn_amd import _lib
+    from heterofusionrcnn_amd._lib import ptr, stream_ptr, check
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(rows * 7 + c)
+    x = (torch.randn(rows, c, generator=g) * 1.5 + 0.3).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    ld = c + 8
+    ybuf = torch.full((rows, ld), 7.0, device="cuda")
+    dybuf = torch.randn(rows, ld, generator=g).cuda()
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    nbytes = L.hf_bn_workspace(rows, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    check(L.hf_bn_relu_fwd_train_ld(rows, c, ptr(x), ptr(gamma), ptr(beta), 1e-3, 0.1, ptr(rm), ptr(rv), mode, ptr(ybuf), ld,
+                                    ptr(mean), ptr(invstd), ptr(ws), nbytes, stream_ptr()), "fwd")
+    dx, dg, db, cs = torch.empty_like(x), torch.empty(c, device="cuda"), torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    check(L.hf_bn_relu_bwd_ld(rows, c, ptr(x), ptr(dybuf), ld, ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), mode, ptr(dx), ptr(dg),
+                              ptr(db), ptr(cs), ptr(ws), nbytes, stream_ptr()), "bwd")
+    xr = x.double().requires_grad_(True)
+    w, b = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    e = torch.nn.functional.elu(xr) if mode == 2 else xr
+    mu, var = e.mean(0), e.var(0, unbiased=False)
+    ref = (e - mu) / torch.sqrt(var + 1e-3) * w + b
+    if mode == 1:
+        ref = torch.relu(ref)
+    ref.backward(dybuf[:, :c].double())
+    assert (ybuf[:, c:] == 7.0).all(), "columns beyond c of the strided output were written"
+    y = ybuf[:, :c].double()
+    if mode == 1:       # an element within rounding of the ReLU threshold may land on either side
+        near = ref.detach().abs() < 1e-5
+        assert torch.allclose(y[~near], ref.detach()[~near], rtol=1e-4, atol=1e-4)
+    else:
+        assert torch.allclose(y, ref.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(mean.double(), mu.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(invstd.double(), 1.0 / torch.sqrt(var.detach() + 1e-3), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rm.double(), 0.1 * mu.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * var.detach(), rtol=1e-4, atol=1e-5)
+    tol = 1e-3 * max(1.0, rows ** 0.5 * 0.1)
+    assert torch.allclose(dg.double(), w.grad, rtol=1e-3, atol=tol) and torch.allclose(db.double(), b.grad, rtol=1e-3, atol=tol)
+    if rows > 1:
+        assert torch.allclose(dx.double(), xr.grad, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(cs.double(), xr.grad.sum(0), rtol=1e-3, atol=tol)

@@ -105,6 +105,32 @@ def test_multi_tensor_adam_inside_a_captured_graph():
         np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.gpu
+def test_multi_tensor_adam_gradients_at_new_addresses_every_step():
+    """eager steps whose gradients never sit where the previous step's did (the old ones are kept alive): every step rewrites
+    and uploads the table while the host is ahead of the device -- the staging ring must hand each upload its own bytes"""
+    from heterofusionrcnn_amd.optim import MultiTensorAdam
+    a, b = _params(9, SHAPES, "cuda"), _params(9, SHAPES, "cuda")
+    oa = MultiTensorAdam(a, lr=1e-2, tf_epsilon=False)
+    ob = torch.optim.Adam(b, lr=1e-2)
+    big = torch.randn(4096, 4096, device="cuda")
+    keep = []
+    for step in range(12):
+        for ps, opt in ((a, oa), (b, ob)):
+            for p in ps:
+                p.grad = None
+            (sum(((p * 1.5).sin() ** 2).sum() for p in ps) * (1.0 + step)).backward()
+            if ps is a:
+                keep.append([p.grad for p in ps])
+                for _ in range(3):
+                    big = big @ big * 1e-4          # device work the host runs ahead of
+            opt.step()
+    torch.cuda.synchronize()
+    assert len({k[0].data_ptr() for k in keep}) == len(keep)
+    for pa, pb in zip(a, b):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
 def test_multi_tensor_adam_has_no_cpu_path():
     from heterofusionrcnn_amd.optim import MultiTensorAdam
     with pytest.raises(RuntimeError, match="no CPU implementation"):
