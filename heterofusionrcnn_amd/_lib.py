@@ -82,6 +82,8 @@ _SIGNATURES = {
     "hf_linear_wgrad_gather": [ctypes.c_longlong, _i, _i, _vp, _vp, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_adam_chunk": [],
     "hf_adam_multi": [_i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp],
+    "hf_copy_multi_max": [],
+    "hf_copy_multi": [_i, _vp, _vp, _vp, _vp],
     "hf_linear_bn_bwd_workspace": [_i],
     "hf_linear_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 18 + [_vp, _sz, _vp],
     "hf_linear_elu_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp],

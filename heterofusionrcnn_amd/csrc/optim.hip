@@ -1,4 +1,5 @@
-// optim.hip -- the Adam update of ALL parameter tensors in one launch (gfx950).
+// optim.hip -- the Adam update of ALL parameter tensors in one launch, and the refresh of a captured step's input slots in one
+// launch (gfx950).
 //
 // The train step of hf/core/trainer.py:71 ends in tf.train.AdamOptimizer.apply_gradients (hf/builders/optimizer_builder.py:59-64).
 // As framework calls that was seven multi-tensor launches per step (the tensor list travels in kernel arguments, 4 KB at a time)
@@ -73,9 +74,64 @@ __global__ __launch_bounds__(kAdamThreads) void adam_multi_kernel(const AdamEntr
     }
 }
 
+// ---- several device-to-device copies in one launch (the refresh of a captured step's input slots) ----
+constexpr int kCopyMax = 64;            // 3 x 8 x 64 = 1.5 KB of kernel arguments
+constexpr int kCopyChunk = 64 * 1024;   // bytes per workgroup
+constexpr int kCopyThreads = 256;
+
+struct CopyList {
+    void *dst[kCopyMax];
+    const void *src[kCopyMax];
+    long long bytes[kCopyMax];
+};
+
+__global__ __launch_bounds__(kCopyThreads) void copy_multi_kernel(CopyList list)
+{
+    const int which = blockIdx.y;
+    const long long total = list.bytes[which];
+    const long long o0 = static_cast<long long>(blockIdx.x) * kCopyChunk;
+    if (o0 >= total) return;
+    const long long n = total - o0 < kCopyChunk ? total - o0 : kCopyChunk;
+    typedef __attribute__((address_space(1))) unsigned char gbyte;
+    gbyte *d = (gbyte *)(static_cast<unsigned char *>(list.dst[which]) + o0);
+    const gbyte *s = (const gbyte *)(static_cast<const unsigned char *>(list.src[which]) + o0);
+    if (((reinterpret_cast<uintptr_t>(list.dst[which]) | reinterpret_cast<uintptr_t>(list.src[which])) & 15) == 0) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(1))) u4 gu4;
+        const long long n16 = n >> 4;
+        for (long long i = threadIdx.x; i < n16; i += kCopyThreads) ((gu4 *)d)[i] = ((const gu4 *)s)[i];
+        for (long long i = (n16 << 4) + threadIdx.x; i < n; i += kCopyThreads) d[i] = s[i];
+    } else {
+        for (long long i = threadIdx.x; i < n; i += kCopyThreads) d[i] = s[i];
+    }
+}
+
 }  // namespace hf
 
 using namespace hf;
+
+HF_API int hf_copy_multi_max(void) { return kCopyMax; }
+
+HF_API int hf_copy_multi(int n, void *const *dst, const void *const *src, const long long *bytes, hf_stream_t stream)
+{
+    if (n < 0 || n > kCopyMax) return HF_EINVAL;
+    if (n == 0) return HF_OK;
+    if (!dst || !src || !bytes) return HF_EINVAL;
+    CopyList list;
+    long long longest = 0;
+    for (int i = 0; i < n; ++i) {
+        if (bytes[i] < 0 || (bytes[i] > 0 && (!dst[i] || !src[i]))) return HF_EINVAL;
+        list.dst[i] = dst[i];
+        list.src[i] = src[i];
+        list.bytes[i] = bytes[i];
+        if (bytes[i] > longest) longest = bytes[i];
+    }
+    if (longest == 0) return HF_OK;
+    const long long chunks = (longest + kCopyChunk - 1) / kCopyChunk;
+    if (chunks > 0x7fffffffLL) return HF_EINVAL;
+    hipLaunchKernelGGL(copy_multi_kernel, dim3(static_cast<unsigned>(chunks), n), dim3(kCopyThreads), 0, as_stream(stream), list);
+    return launch_status();
+}
 
 HF_API int hf_adam_chunk(void) { return kAdamChunk; }
 

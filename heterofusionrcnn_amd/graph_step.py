@@ -24,8 +24,37 @@ frame per GPU (BASELINE config 4: a batch of 8 over 8 GPUs).  Here the step is c
 
 No work is skipped or cached: a replay launches exactly the kernels the eager step launches.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
+from ._lib import check, stream_ptr
+
+
+def copy_many(dst, src):
+    """dst[i] <- src[i] for lists of device tensors of ANY mix of dtypes in one launch per 64 pairs (csrc/optim.hip,
+    hf_copy_multi): torch._foreach_copy_ falls back to one copy launch per tensor as soon as the list mixes dtypes (int32
+    neighbour tables, fp32 points, int64 labels ...), ~40 launches of 5 us each in front of every replayed step.  Pairs that are
+    not plain byte copies (a dtype change, a non-contiguous side) go to the framework."""
+    L = _lib.lib()
+    fast, slow = [], []
+    for d, s_ in zip(dst, src):
+        ok = (d.is_cuda and s_.is_cuda and d.device == s_.device and d.dtype == s_.dtype and d.shape == s_.shape and
+              d.is_contiguous() and s_.is_contiguous())
+        (fast if ok else slow).append((d, s_))
+    cap = L.hf_copy_multi_max()
+    for i in range(0, len(fast), cap):
+        part = fast[i:i + cap]
+        n = len(part)
+        d_arr = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in part])
+        s_arr = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in part])
+        b_arr = (ctypes.c_longlong * n)(*[d.numel() * d.element_size() for d, _ in part])
+        check(L.hf_copy_multi(n, d_arr, s_arr, b_arr, stream_ptr()), "copy_multi")
+    if slow:
+        torch._foreach_copy_([d for d, _ in slow], [s_ for _, s_ in slow])
+
 
 
 def tree_tensors(obj, out=None):
@@ -280,7 +309,8 @@ class TrainStep:
                 dst.append(self.inputs[k] if not self.inputs[k].requires_grad else self.inputs[k].detach())
                 src.append(v)
         if dst:
-            torch._foreach_copy_(dst, src)
+            with torch.no_grad():
+                copy_many(dst, src)
 
     def __call__(self, geometry=None, **inputs):
         self.load(geometry, **inputs)

@@ -549,6 +549,15 @@ int hf_adam_chunk(void);
 int hf_adam_multi(int num_chunks, const hf_adam_entry *table, const int *chunk_map, const float *step, float lr, float beta1,
                   float beta2, float eps, float grad_scale, int mode, hf_stream_t stream);
 
+/* ------------------------------------------------------------------ feeding a captured step */
+
+/* n (<= hf_copy_multi_max()) device-to-device copies in ONE launch: dst[i] <- src[i], bytes[i] each (the three arrays live on the
+ * HOST; they travel in the kernel arguments).  The feed_dict of one sess.run (hf/core/trainer.py:216-226) becomes, for a captured
+ * step, the refresh of its static input slots: ~40 tensors per step (points, labels, the neighbour tables of every level) that
+ * the framework would copy with one launch each.  Overlapping ranges are not supported. */
+int hf_copy_multi_max(void);
+int hf_copy_multi(int n, void *const *dst, const void *const *src, const long long *bytes, hf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -409,3 +409,29 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(mode):
     assert d["n_gpus"] == 2 and d["scaling"] == mode and d["config"]["frames_per_gpu"] == per and d["config"]["global_batch"] == 2 * per
     assert d["config"]["hip_graph"] == (mode == "strong") and np.isfinite(d["value"]) and d["value"] > 0
     assert "rehearsal" in d["config"]
+
+
+@pytest.mark.gpu
+def test_copy_many_mixed_dtypes_one_launch():
+    """graph_step.copy_many (hf_copy_multi): 150 pairs of mixed dtypes, odd byte counts, unaligned views, an empty tensor and a
+    non-contiguous pair (which goes to the framework) -- every destination equals its source, nothing beside them is touched"""
+    from heterofusionrcnn_amd.graph_step import copy_many
+    g = torch.Generator().manual_seed(3)
+    dst, src, guards = [], [], []
+    dtypes = [torch.float32, torch.int32, torch.int64, torch.uint8, torch.float64, torch.int16]
+    for i in range(150):
+        dt = dtypes[i % len(dtypes)]
+        n = [0, 1, 3, 17, 255, 4096, 70001, 300000][i % 8]
+        s = (torch.rand(n + 9, generator=g) * 100).to(dt).cuda()
+        d = torch.full((n + 9,), 5, dtype=dt, device="cuda")
+        off = i % 5                                  # views that start off the 16-byte grid
+        src.append(s[off:off + n]); dst.append(d[off:off + n]); guards.append((d, off, n))
+    a = torch.arange(24, device="cuda", dtype=torch.float32).view(4, 6)
+    b = torch.zeros(6, 4, device="cuda")
+    src.append(a.t()); dst.append(b)                 # non-contiguous source
+    copy_many(dst, src)
+    torch.cuda.synchronize()
+    for d, s in zip(dst, src):
+        assert torch.equal(d, s)
+    for d, off, n in guards:
+        assert (d[:off] == 5).all() and (d[off + n:] == 5).all()
