@@ -531,6 +531,9 @@ def parse_args(argv=None):
     ap.add_argument("--x-branch-stream", choices=("auto", "on", "off"), default="auto",
                     help="the X-transformation branch of every X-Conv on a side HIP stream (pointcnn.CONCURRENT_X_BRANCH); auto = on, except "
                          "for enqueued steps under DistributedDataParallel")
+    ap.add_argument("--lift-branch-max-rows", type=int, default=-1,
+                    help="with the X branch on a side stream: the lifting branch of X-Conv layers with at most this many rows (B*P*K) "
+                         "goes on a second one (default: pointcnn.CONCURRENT_LIFT_BRANCH_MAX_ROWS)")
     ap.add_argument("--gemm-tuning", default="off",
                     help="off (default): the library's own heuristic; auto: load heterofusionrcnn_amd/tuned_gemms.csv if present "
                          "(library-GEMM selections per shape, PyTorch TunableOp); tune:<file>: time the candidates of every shape of "
@@ -729,6 +732,8 @@ def main():
         # measured: -1.6 ms at 1 frame (replayed), -1.5 ms at 8 (enqueued).  Not under DistributedDataParallel (several ranks, enqueued steps):
         # its bucket hooks copy gradients as they appear, on whatever stream the producing node ran
         pointcnn_mod.CONCURRENT_X_BRANCH = args.x_branch_stream == "on" or (args.x_branch_stream == "auto" and (use_graph or world == 1))
+        if args.lift_branch_max_rows >= 0:
+            pointcnn_mod.CONCURRENT_LIFT_BRANCH_MAX_ROWS = args.lift_branch_max_rows
         from heterofusionrcnn_amd.optim import MultiTensorAdam
         make_opt = ((lambda ps, capturable: MultiTensorAdam(ps, lr=lr, tf_epsilon=False)) if args.optimizer == "hf" else
                     (lambda ps, capturable: torch.optim.Adam(ps, lr=lr, fused=True, capturable=capturable)))

@@ -20,6 +20,7 @@ The weight layouts are TensorFlow's (HWIO / depthwise HW, in, multiplier) so tha
 tests/test_pointcnn.py checks the einsum forms against torch.nn.functional.conv2d with the same weights.
 TensorFlow cannot be imported here: parity unpinned against reference outputs.
 """
+import contextlib
 import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -523,20 +524,32 @@ class SeparableK(nn.Module):
 
 
 # The X-transformation branch of an X-Conv (x0 -> x1 -> x2 on (B,P,K*3): rows = P) and its lifting branch (lift0 -> lift1 on
-# (B,P,K,3): rows = P*K) meet only in the X x F_* product (pointcnn.py:96-133).  With CONCURRENT_X_BRANCH the X branch is
-# enqueued on a side HIP stream: its ~35 small launches per layer (forward + backward: autograd runs a node's backward on the
-# stream its forward ran on) overlap the lifting branch instead of queueing behind it; inside a captured step the fork and the
-# join become edges of the graph.  Off by default; graph_step.TrainStep / bench.py switch it on below 8 frames per GPU, where
-# the kernels of one branch do not fill the chip.
+# (B,P,K,3): rows = P*K) read COORDINATES only -- the neighbours' offsets P' = P - p -- and meet the feature chain only in the
+# X x F_* product (pointcnn.py:96-133).  With CONCURRENT_X_BRANCH each of the two is enqueued on its own side HIP stream: their
+# small launches (forward + backward: autograd runs a node's backward on the stream its forward ran on) overlap the feature chain
+# instead of queueing inside it; inside a captured step the forks and joins become edges of the graph.  When the caller has forked
+# the side streams once, after the geometry is in place (PointCnnBackbone.forward: `ahead`), the branches of LATER layers do not
+# wait for the feature chain of earlier ones at all: they run ahead, and the chain finds X and F_delta ready.  Off by default;
+# graph_step.TrainStep / bench.py switch it on where the kernels of one branch do not fill the chip.
 CONCURRENT_X_BRANCH = False
+CONCURRENT_X_BRANCH_MIN_POINTS = 0      # only layers with at least this many output points (B*P) fork
+CONCURRENT_LIFT_BRANCH_MAX_ROWS = 65536  # (with CONCURRENT_X_BRANCH) the lifting branch of layers with at most this many rows (B*P*K) on a second side stream
+CONCURRENT_RUN_AHEAD = False            # (with CONCURRENT_X_BRANCH) fork once per forward pass, not once per layer
 _side_streams = {}
 
 
-def _side_stream(device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+def _side_stream(device, which=0):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
+
+
+def fork_side_streams(device):
+    """the side streams of the coordinate-only branches pick up from the current stream (call once the geometry is in place)"""
+    cur = torch.cuda.current_stream(device)
+    for which in (0, 1):
+        _side_stream(device, which).wait_stream(cur)
 
 
 class XConv(nn.Module):
@@ -572,35 +585,50 @@ class XConv(nn.Module):
             _, idx = knn_point(self.k * self.d, pts, qrs)
             return idx[:, :, ::self.d].contiguous() if self.d > 1 else idx
 
-    def forward(self, pts, fts, qrs, idx=None, inverse=None, skip=None):
+    def forward(self, pts, fts, qrs, idx=None, inverse=None, skip=None, ahead=False):
         """inverse = index_inverse(idx, N) prepared with the geometry: the gradient of the feature gather then gathers too.
-        skip (B,P,Cs): returns [x-conv output | skip] (the concat of an X-DeConv with the encoder features, pointcnn.py:349)"""
+        skip (B,P,Cs): returns [x-conv output | skip] (the concat of an X-DeConv with the encoder features, pointcnn.py:349).
+        ahead: the caller forked the side streams after pts / qrs / idx were in place (fork_side_streams)"""
         idx = idx if idx is not None else self.neighbours(pts, qrs)
         b, p, k = idx.shape
-        local = group_point(pts, idx) - qrs.unsqueeze(2)     # (B,P,K,3)  P' <- P - p
         bn1 = self.lift1.post.bn
-        x = side = None
-        if self.with_x and CONCURRENT_X_BRANCH and local.is_cuda:
-            # fork: the X-transformation on the side stream, from `local` (made on this stream) to the (B,P,K,K) matrices
-            cur = torch.cuda.current_stream(local.device)
-            side = _side_stream(local.device)
-            side.wait_stream(cur)
-            local.record_stream(side)
+        c_delta = self.lift1.linear.out_features
+        x = side = lside = None
+        concurrent = self.with_x and CONCURRENT_X_BRANCH and pts.is_cuda and b * p >= CONCURRENT_X_BRANCH_MIN_POINTS
+        if concurrent:
+            # fork: the X-transformation on a side stream, from the offsets (made there too) to the (B,P,K,K) matrices
+            cur = torch.cuda.current_stream(pts.device)
+            side = _side_stream(pts.device)
+            if not ahead:
+                side.wait_stream(cur)
             with torch.cuda.stream(side):
-                x = self._x_transform(local, b, p, k)
-        gather = self.with_x and fts is not None and _gather_fusable(local, self.lift1.linear.out_features, fts, self.conv.depthwise, inverse)
-        if gather:
-            f = dense_chain(self.lift0, self.lift1, local)    # F_delta alone: the neighbours' features are read in place below
-        elif fts is not None and _fusable(bn1, fts, self.lift1.linear.out_features, self.lift1.linear.out_features + fts.shape[-1]):
+                x = self._x_transform(group_point(pts, idx) - qrs.unsqueeze(2), b, p, k)
+            if b * p * k <= CONCURRENT_LIFT_BRANCH_MAX_ROWS:
+                lside = _side_stream(pts.device, 1)
+                if not ahead:
+                    lside.wait_stream(cur)
+        gather = self.with_x and fts is not None and _gather_fusable(pts, c_delta, fts, self.conv.depthwise, inverse)
+        fuse_concat = (not gather) and fts is not None and _fusable(bn1, fts, c_delta, c_delta + fts.shape[-1])
+        # the coordinate-only part of the lifting branch (on its side stream when there is one) ...
+        with torch.cuda.stream(lside) if lside is not None else contextlib.nullcontext():
+            local = group_point(pts, idx) - qrs.unsqueeze(2)     # (B,P,K,3)  P' <- P - p
+            if gather:
+                f = dense_chain(self.lift0, self.lift1, local)    # F_delta alone: the neighbours' features are read in place below
+            elif fuse_concat:
+                f = linear_nobias(self.lift0(local), self.lift1.linear.weight)      # z of the second lifting layer
+            else:
+                f = self.lift1(self.lift0(local))                 # F_delta
+        if lside is not None:                                  # join: this stream's next kernel reads f
+            cur.wait_stream(lside)
+            f.record_stream(cur)
+        # ... and the part that reads the previous layer's features
+        if fuse_concat:
             # F_* <- [F_delta, F]: the second lifting layer's BatchNorm writes into the concat, the gather fills the rest
-            z = linear_nobias(self.lift0(local), self.lift1.linear.weight)
             off, ent = inverse if inverse is not None else (None, None)
-            f = _BNConcatGroup.apply(z.reshape(-1, z.shape[-1]), bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps,
+            f = _BNConcatGroup.apply(f.reshape(-1, f.shape[-1]), bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps,
                                      bn1.momentum, _bn_mode(bn1), fts.contiguous(), idx, off, ent)
-        else:
-            f = self.lift1(self.lift0(local))                 # F_delta
-            if fts is not None:
-                f = concat_group(f, fts, idx, inverse)         # F_* <- [F_delta, F]: gathered straight into the concat
+        elif not gather and fts is not None:
+            f = concat_group(f, fts, idx, inverse)             # F_* <- [F_delta, F]: gathered straight into the concat
         if self.with_x:
             if side is not None:                               # join: this stream's next kernel reads x
                 cur.wait_stream(side)
@@ -699,8 +727,11 @@ class PointCnnBackbone(nn.Module):
         g = geometry if geometry is not None else self.geometry(xyz)
         pts = g["pts"]
         fts = [features]
+        ahead = CONCURRENT_X_BRANCH and CONCURRENT_RUN_AHEAD and xyz.is_cuda
+        if ahead:
+            fork_side_streams(xyz.device)      # the geometry is in place: the coordinate-only branches of every layer may start
         for li, m in enumerate(self.enc):
-            fts.append(m(pts[li], fts[-1], pts[li + 1], g["enc"][li], g.get("enc_inv", [None] * len(self.enc))[li]))
+            fts.append(m(pts[li], fts[-1], pts[li + 1], g["enc"][li], g.get("enc_inv", [None] * len(self.enc))[li], ahead=ahead))
         if taps is not None:
             # a clean cut: the decoder (and everything after it) reads detached copies that are leaves of their own graph, so
             # d loss / d copy holds the downstream paths only; the encoder's own chain (layer i+1 reads layer i) stays on the
@@ -711,7 +742,8 @@ class PointCnnBackbone(nn.Module):
         cur = None
         for li, (k, d, pi, qi) in enumerate(self.cfg.xdconv):
             src = fts[pi + 1] if li == 0 else cur
-            x = self.dec[li](pts[pi + 1], src, pts[qi + 1], g["dec"][li], g.get("dec_inv", [None] * len(self.dec))[li], skip=fts[qi + 1])
+            x = self.dec[li](pts[pi + 1], src, pts[qi + 1], g["dec"][li], g.get("dec_inv", [None] * len(self.dec))[li], skip=fts[qi + 1],
+                             ahead=ahead)
             cur = self.fuse[li](x)                                   # x = [x-deconv | encoder features of the query layer]
         out = cur if cur is not None else fts[-1]        # no decoder (the RCNN's extractor): the last encoder layer
         for layer, rate in zip(self.fc, self.fc_drop):

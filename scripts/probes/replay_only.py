@@ -13,6 +13,11 @@ from heterofusionrcnn_amd.pipeline import GeometryPrefetcher
 from bench import kitti_frustum, N0, IMG_C, IMG_H, IMG_W, KITTI_P2
 FR = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 pointcnn_mod.CONCURRENT_X_BRANCH = (sys.argv[2] if len(sys.argv) > 2 else "on") == "on"
+pointcnn_mod.CONCURRENT_X_BRANCH_MIN_POINTS = int(os.environ.get("HF_X_MIN_POINTS", "0"))
+ONLY_AB = os.environ.get("HF_ONLY_AB") == "1"
+pointcnn_mod.CONCURRENT_LIFT_BRANCH_MAX_ROWS = int(os.environ.get("HF_LIFT", "131072"))
+pointcnn_mod.CONCURRENT_RUN_AHEAD = os.environ.get("HF_AHEAD", "1") == "1"
+print("lift branch on a side stream up to %s rows, run ahead %s" % (pointcnn_mod.CONCURRENT_LIFT_BRANCH_MAX_ROWS, pointcnn_mod.CONCURRENT_RUN_AHEAD))
 rng = np.random.default_rng(0)
 cfg = rpn_mod.rpn_multiclass(IMG_C)
 model = rpn_mod.RpnModel(cfg).cuda()
@@ -35,6 +40,9 @@ def timed(fn, n=40):
 print("frames %d, X branch on a side stream: %s" % (FR, pointcnn_mod.CONCURRENT_X_BRANCH))
 print("A replay alone                    %.3f ms per step (host %.3f)" % timed(lambda: train.graph.replay()))
 print("B slots refreshed + replay        %.3f ms per step (host %.3f)" % timed(lambda: train(geometry=geo)))
+print("fork threshold (points): %d" % pointcnn_mod.CONCURRENT_X_BRANCH_MIN_POINTS)
+if ONLY_AB:
+    sys.exit(0)
 for depth in (1, 2, 3):
     pre = GeometryPrefetcher(model.geometry, depth=depth, group=1)
     for _ in range(pre.capacity): pre.submit(xyz)
