@@ -539,6 +539,8 @@ def parse_args(argv=None):
                          "(library-GEMM selections per shape, PyTorch TunableOp); tune:<file>: time the candidates of every shape of "
                          "this run and record them in <file>.  Measured in round 4: 0 .. 6 %% at one frame per GPU depending on the box, "
                          "no numerical check of the candidates by default -- not worth shipping on")
+    ap.add_argument("--blas", choices=("default", "rocblas", "hipblaslt"), default="default",
+                    help="diagnostic: which vendor library the framework's matmuls go to (torch.backends.cuda.preferred_blas_library)")
     ap.add_argument("--with-vgg", action="store_true",
                     help="rpn_multiclass only: run the image branch too (inference.ImgVggPyr forward + backward on the vendor "
                          "library, trained with the RPN: hf/core/models/rpn_model.py:126-127,223) instead of feeding a resident "
@@ -654,6 +656,10 @@ def main():
         tuned = gemm_tuning.enable(args.gemm_tuning[5:], tune=True)
     elif args.gemm_tuning == "auto":
         tuned = gemm_tuning.enable()
+
+    if args.blas != "default":
+        import torch
+        torch.backends.cuda.preferred_blas_library("cublas" if args.blas == "rocblas" else "cublaslt")
 
     timer = EventTimer()
     headline = lambda radius, nsample, xyz1, xyz2, center=True: (xyz1.shape[1] == N0 and xyz2.shape[1] == SA[0][0] and nsample == KNN)

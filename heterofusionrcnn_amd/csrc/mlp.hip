@@ -86,12 +86,32 @@ __device__ __forceinline__ void reduce_rows(float (&a)[VEC], float (&b)[VEC], in
 // normalisation and the backward pass then see elu(x), computed on load -- the activation never exists in memory.
 constexpr int kBnRelu = 1, kBnEluIn = 2;
 
+// The streaming passes below keep kBnUnroll rows of a thread in flight: one 16-byte load per thread and iteration, waited for at
+// once (what the plain loop compiled to), left every wave idle for a full memory round trip per row -- 2.3-3 TB/s on the
+// million-row tensors of the X-Conv layers; with four (eight in the two-operand passes) requests per thread outstanding the
+// passes stream (scripts/probes/bn_stream_timing.py).  The ELU on load is exp(x) - 1 on the hardware exponential -- TensorFlow's
+// own formula for tf.nn.elu (relu_op_functor.h: features.exp() - 1) -- three instructions instead of expm1f's 25 per element, which
+// at 64 channels x 10^6 rows was as long as the memory time itself; its slope is the same exponential (EluGrad: (y + 1) dy).
+constexpr int kBnUnroll = 4;
+
+// elu(x) and, on request, its slope, branch-free (select, no exec masking around the exponential)
+__device__ __forceinline__ float elu_stream(float x) { return x > 0.0f ? x : __builtin_amdgcn_exp2f(x * 1.44269504088896340736f) - 1.0f; }
+__device__ __forceinline__ float elu_stream(float x, float &slope)
+{
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+    slope = x > 0.0f ? 1.0f : e;
+    return x > 0.0f ? x : e - 1.0f;
+}
+
+// A thread's rows are rsub, rsub + rpb, ... < local (rows of the block); operands are addressed as a uniform block base plus a 32-bit
+// element offset (bn_geom keeps rows_per_block x row stride below 2^31).
 // partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over the block's rows
-template <int VEC>
+template <int VEC, bool ELU>
 __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
-                                const float *__restrict__ x, float *__restrict__ partial, int elu_in)
+                                const float *__restrict__ x, float *__restrict__ partial)
 {
     extern __shared__ float smem[];
+    typedef typename VecT<VEC>::type V;
     const int t = threadIdx.x;
     const int cvec = t % cv, rsub = t / cv;
     const long long r0 = blockIdx.x * rows_per_block;
@@ -99,11 +119,22 @@ __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long lon
     float s[VEC], q[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q[i] = 0.f; }
-    for (long long r = r0 + rsub; r < r1; r += rpb) {
-        const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
+    auto add = [&](const V &v) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { float f = vget<VEC>(v, i); if (elu_in) f = elu_fwd(f); s[i] += f; q[i] += f * f; }
+        for (int i = 0; i < VEC; ++i) { float f = vget<VEC>(v, i); if (ELU) f = elu_stream(f); s[i] += f; q[i] += f * f; }
+    };
+    const int local = static_cast<int>(r1 - r0);
+    const float *bx = x + r0 * c;
+    const int sx = rpb * c;
+    int ox = rsub * c + cvec * VEC, row = rsub;
+    for (; row + (kBnUnroll - 1) * rpb < local; row += kBnUnroll * rpb, ox += kBnUnroll * sx) {
+        V v[kBnUnroll];
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) v[u] = ldv<VEC>(bx + ox + u * sx);
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) add(v[u]);
     }
+    for (; row < local; row += rpb, ox += sx) add(ldv<VEC>(bx + ox));
     reduce_rows<VEC>(s, q, cv, rpb, cvec, rsub, smem);
     if (rsub == 0) {
         // partial[which][channel][block]: the finalize kernel reads one channel's partials contiguously
@@ -159,12 +190,13 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, 
 }
 
 // y = relu?(gamma*invstd*(x-mean) + beta)
-template <int VEC>
+template <int VEC, bool ELU>
 __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                 const float *__restrict__ x, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, const float *__restrict__ mean,
                                 const float *__restrict__ invstd, int relu, float *__restrict__ y, long long ldy)
 {
+    typedef typename VecT<VEC>::type V;
     const int t = threadIdx.x;
     const int cvec = t % cv, rsub = t / cv;
     float a[VEC], b[VEC], mu[VEC];   // y = a (x - mu) + beta: the difference first, as the reference graph forms it
@@ -177,23 +209,35 @@ __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long lon
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (long long r = r0 + rsub; r < r1; r += rpb) {
-        const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
-        typename VecT<VEC>::type o;
+    auto one = [&](const V &v) -> V {
+        V o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float xv = vget<VEC>(v, i);
-            if (relu & kBnEluIn) xv = elu_fwd(xv);
+            if (ELU) xv = elu_stream(xv);
             float h = a[i] * (xv - mu[i]) + b[i];
             if (relu & kBnRelu) h = fmaxf(h, 0.0f);
             vset<VEC>(o, i, h);
         }
-        stv<VEC>(y + r * ldy + cvec * VEC, o);   // ldy >= c: the row may be a slice of a wider (concat) buffer
+        return o;
+    };
+    const int local = static_cast<int>(r1 - r0);
+    const float *bx = x + r0 * c;
+    float *by = y + r0 * ldy;                         // ldy >= c: the row may be a slice of a wider (concat) buffer
+    const int sx = rpb * c, sy = rpb * static_cast<int>(ldy);
+    int ox = rsub * c + cvec * VEC, oy = rsub * static_cast<int>(ldy) + cvec * VEC, row = rsub;
+    for (; row + (kBnUnroll - 1) * rpb < local; row += kBnUnroll * rpb, ox += kBnUnroll * sx, oy += kBnUnroll * sy) {
+        V v[kBnUnroll];
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) v[u] = ldv<VEC>(bx + ox + u * sx);
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) stv<VEC>(by + oy + u * sy, one(v[u]));
     }
+    for (; row < local; row += rpb, ox += sx, oy += sy) stv<VEC>(by + oy, one(ldv<VEC>(bx + ox)));
 }
 
 // partial[blk][0][c] = sum dh, partial[blk][1][c] = sum dh*xhat  (dh = dy masked by the ReLU of a*x+b)
-template <int VEC>
+template <int VEC, bool ELU>
 __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                      const float *__restrict__ x, const float *__restrict__ dy,
                                      const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -201,6 +245,7 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
                                      float *__restrict__ partial, long long lddy)
 {
     extern __shared__ float smem[];
+    typedef typename VecT<VEC>::type V;
     const int t = threadIdx.x;
     const int cvec = t % cv, rsub = t / cv;
     float a[VEC], b[VEC], mu[VEC], is[VEC], s1[VEC], s2[VEC];
@@ -214,19 +259,29 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (long long r = r0 + rsub; r < r1; r += rpb) {
-        const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
-        const typename VecT<VEC>::type g = ldv<VEC>(dy + r * lddy + cvec * VEC);
+    auto add = [&](const V &v, const V &g) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float xv = vget<VEC>(v, i);
-            if (relu & kBnEluIn) xv = elu_fwd(xv);
+            if (ELU) xv = elu_stream(xv);
             float dh = vget<VEC>(g, i);
             if ((relu & kBnRelu) && !(a[i] * (xv - mu[i]) + b[i] > 0.0f)) dh = 0.0f;
             s1[i] += dh;
             s2[i] += dh * ((xv - mu[i]) * is[i]);
         }
+    };
+    const int local = static_cast<int>(r1 - r0);
+    const float *bx = x + r0 * c, *bg = dy + r0 * lddy;
+    const int sx = rpb * c, sg = rpb * static_cast<int>(lddy);
+    int ox = rsub * c + cvec * VEC, og = rsub * static_cast<int>(lddy) + cvec * VEC, row = rsub;
+    for (; row + (kBnUnroll - 1) * rpb < local; row += kBnUnroll * rpb, ox += kBnUnroll * sx, og += kBnUnroll * sg) {
+        V v[kBnUnroll], g[kBnUnroll];
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) { v[u] = ldv<VEC>(bx + ox + u * sx); g[u] = ldv<VEC>(bg + og + u * sg); }
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) add(v[u], g[u]);
     }
+    for (; row < local; row += rpb, ox += sx, og += sg) add(ldv<VEC>(bx + ox), ldv<VEC>(bg + og));
     reduce_rows<VEC>(s1, s2, cv, rpb, cvec, rsub, smem);
     if (rsub == 0) {
 #pragma unroll
@@ -250,7 +305,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int c, int nblk, c
 }
 
 // dx = gamma*invstd*(dh - dbeta/R - xhat*dgamma/R)
-template <int VEC>
+template <int VEC, bool ELU>
 __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                  const float *__restrict__ x, const float *__restrict__ dy,
                                  const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -259,6 +314,7 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
                                  float *__restrict__ dx, float *__restrict__ colsum_partial, long long lddy)
 {
     extern __shared__ float smem[];
+    typedef typename VecT<VEC>::type V;
     const int t = threadIdx.x;
     const int cvec = t % cv, rsub = t / cv;
     const float inv_r = 1.0f / static_cast<float>(rows);
@@ -275,24 +331,36 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (long long r = r0 + rsub; r < r1; r += rpb) {
-        const typename VecT<VEC>::type v = ldv<VEC>(x + r * c + cvec * VEC);
-        const typename VecT<VEC>::type g = ldv<VEC>(dy + r * lddy + cvec * VEC);
-        typename VecT<VEC>::type o;
+    auto one = [&](const V &v, const V &g) -> V {
+        V o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const float xraw = vget<VEC>(v, i);
-            const float xv = (relu & kBnEluIn) ? elu_fwd(xraw) : xraw;
+            float slope = 1.0f;
+            float xv = vget<VEC>(v, i);
+            if (ELU) xv = elu_stream(xv, slope);
             float dh = vget<VEC>(g, i);
             if ((relu & kBnRelu) && !(a[i] * (xv - mu[i]) + b[i] > 0.0f)) dh = 0.0f;
             const float xhat = (xv - mu[i]) * is[i];
             float d = a[i] * (dh - c1[i] - xhat * c2[i]);
-            if (relu & kBnEluIn) d = d * elu_slope(xraw);
+            if (ELU) d = d * slope;
             cs[i] += d;
             vset<VEC>(o, i, d);
         }
-        stv<VEC>(dx + r * c + cvec * VEC, o);
+        return o;
+    };
+    const int local = static_cast<int>(r1 - r0);
+    const float *bx = x + r0 * c, *bg = dy + r0 * lddy;
+    float *bo = dx + r0 * c;
+    const int sx = rpb * c, sg = rpb * static_cast<int>(lddy);
+    int ox = rsub * c + cvec * VEC, og = rsub * static_cast<int>(lddy) + cvec * VEC, row = rsub;
+    for (; row + (kBnUnroll - 1) * rpb < local; row += kBnUnroll * rpb, ox += kBnUnroll * sx, og += kBnUnroll * sg) {
+        V v[kBnUnroll], g[kBnUnroll];
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) { v[u] = ldv<VEC>(bx + ox + u * sx); g[u] = ldv<VEC>(bg + og + u * sg); }
+#pragma unroll
+        for (int u = 0; u < kBnUnroll; ++u) stv<VEC>(bo + ox + u * sx, one(v[u], g[u]));
     }
+    for (; row < local; row += rpb, ox += sx, og += sg) stv<VEC>(bo + ox, one(ldv<VEC>(bx + ox), ldv<VEC>(bg + og)));
     if (colsum_partial) {  // column sums of dx = the bias gradient of the Linear that produced x
         reduce_rows<VEC>(cs, unused, cv, rpb, cvec, rsub, smem);
         if (rsub == 0) {
@@ -688,6 +756,49 @@ void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, nblk, partial, dgamma, dbeta);
 }
 
+// the streaming passes by vector width and activation-on-load
+template <typename F4E, typename F4, typename F1E, typename F1>
+static void bn_dispatch(const BnGeom &g, bool elu, F4E f4e, F4 f4, F1E f1e, F1 f1)
+{
+    if (g.vec == 4) { if (elu) f4e(); else f4(); }
+    else { if (elu) f1e(); else f1(); }
+}
+
+static void launch_bn_stats(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, float *partial, bool elu)
+{
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+#define HF_BN_L(V, E) [&] { hipLaunchKernelGGL((bn_stats_kernel<V, E>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, partial); }
+    bn_dispatch(g, elu, HF_BN_L(4, true), HF_BN_L(4, false), HF_BN_L(1, true), HF_BN_L(1, false));
+#undef HF_BN_L
+}
+
+static void launch_bn_apply(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *gamma, const float *beta,
+                            const float *mean, const float *invstd, int relu, float *y, long long ldy)
+{
+#define HF_BN_L(V, E) [&] { hipLaunchKernelGGL((bn_apply_kernel<V, E>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, gamma, beta, mean, invstd, relu, y, ldy); }
+    bn_dispatch(g, (relu & kBnEluIn) != 0, HF_BN_L(4, true), HF_BN_L(4, false), HF_BN_L(1, true), HF_BN_L(1, false));
+#undef HF_BN_L
+}
+
+static void launch_bn_bwd_reduce(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
+                                 const float *beta, const float *mean, const float *invstd, int relu, float *partial, long long lddy)
+{
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+#define HF_BN_L(V, E) [&] { hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, E>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy, gamma, beta, mean, invstd, relu, partial, lddy); }
+    bn_dispatch(g, (relu & kBnEluIn) != 0, HF_BN_L(4, true), HF_BN_L(4, false), HF_BN_L(1, true), HF_BN_L(1, false));
+#undef HF_BN_L
+}
+
+static void launch_bn_bwd_dx(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
+                             const float *beta, const float *mean, const float *invstd, const float *dgamma, const float *dbeta, int relu,
+                             float *dx, float *colsum_partial, long long lddy)
+{
+    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+#define HF_BN_L(V, E) [&] { hipLaunchKernelGGL((bn_bwd_dx_kernel<V, E>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy, gamma, beta, mean, invstd, dgamma, dbeta, relu, dx, colsum_partial, lddy); }
+    bn_dispatch(g, (relu & kBnEluIn) != 0, HF_BN_L(4, true), HF_BN_L(4, false), HF_BN_L(1, true), HF_BN_L(1, false));
+#undef HF_BN_L
+}
+
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
 }  // namespace hf
@@ -702,6 +813,11 @@ HF_API size_t hf_bn_workspace(long long rows, int c)
 
 // vec = 4 needs 16-byte rows on every strided operand too
 static bool ld_ok4(long long ld) { return ld % 4 == 0; }
+// the streaming kernels address a block's rows with 32-bit element offsets (rows of a block + one unrolled step, times the row stride)
+static bool bn_offsets_fit(const BnGeom &g, long long ld)
+{
+    return (g.rows_per_block + static_cast<long long>(kBnUnroll + 1) * g.rpb) * ld < (1ll << 31);
+}
 
 HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps,
                                    float momentum, float *running_mean, float *running_var, int relu, float *y, long long ldy,
@@ -712,6 +828,7 @@ HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const 
     if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
     BnGeom g = bn_geom(rows, c);
     if (g.vec == 4 && !(aligned16(x) && aligned16(y) && ld_ok4(ldy))) return HF_EINVAL;
+    if (!bn_offsets_fit(g, ldy)) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     BnSmallGeom sg;
     if (bn_small_geom(rows, c, sg)) {
@@ -720,21 +837,10 @@ HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const 
         return launch_status();
     }
     float *partial = static_cast<float *>(workspace);
-    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial, (relu & kBnEluIn) ? 1 : 0);
-    else
-        hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial, (relu & kBnEluIn) ? 1 : 0);
+    launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd);
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
-    else
-        hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
+    launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
     return launch_status();
 }
 
@@ -757,13 +863,7 @@ HF_API int hf_bn_stats(long long rows, int c, const float *x, float eps, float m
     if (g.vec == 4 && !aligned16(x)) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
-    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial, 0);
-    else
-        hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, partial, 0);
+    launch_bn_stats(g, st, rows, c, x, partial, false);
     launch_bn_stats_finalize(rows, c, g.nblk, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd, st);
     return launch_status();
 }
@@ -775,12 +875,7 @@ HF_API int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const floa
     BnGeom g = bn_geom(rows, c);
     if (g.vec == 4 && !(aligned16(x) && aligned16(y))) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, gamma, beta, mean, invstd, relu, y, static_cast<long long>(c));
-    else
-        hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, gamma, beta, mean, invstd, relu, y, static_cast<long long>(c));
+    launch_bn_apply(g, st, rows, c, x, gamma, beta, mean, invstd, relu, y, static_cast<long long>(c));
     return launch_status();
 }
 
@@ -795,6 +890,7 @@ HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float 
     if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
     BnGeom g = bn_geom(rows, c);
     if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx) && ld_ok4(lddy))) return HF_EINVAL;
+    if (!bn_offsets_fit(g, lddy)) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     BnSmallGeom sg;
     if (bn_small_geom(rows, c, sg)) {
@@ -803,21 +899,10 @@ HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float 
         return launch_status();
     }
     float *partial = static_cast<float *>(workspace);
-    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
-    else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
+    launch_bn_bwd_reduce(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
     float *cpart = dx_colsum ? partial : nullptr;  // the reduce partials were consumed by the finalize kernel above
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy);
-    else
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy);
+    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy);
     if (dx_colsum)
         hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, cpart, dx_colsum);
     return launch_status();
@@ -841,15 +926,7 @@ HF_API int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float 
     BnGeom g = bn_geom(rows, c);
     if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx))) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
-    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-    if (g.vec == 4)
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx,
-                           static_cast<float *>(nullptr), static_cast<long long>(c));
-    else
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                           g.rows_per_block, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx,
-                           static_cast<float *>(nullptr), static_cast<long long>(c));
+    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, nullptr, static_cast<long long>(c));
     return launch_status();
 }
 
@@ -868,13 +945,7 @@ HF_API int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z
         BnGeom g = bn_geom(rows, c);
         if (g.vec == 4 && !aligned16(z)) return HF_EINVAL;
         float *partial = static_cast<float *>(workspace);
-        const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-        if (g.vec == 4)
-            hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                               g.rows_per_block, z, partial, 0);
-        else
-            hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb,
-                               g.rows_per_block, z, partial, 0);
+        launch_bn_stats(g, st, rows, c, z, partial, false);
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps, momentum,
                            running_mean, running_var, mean, invstd);
     }
