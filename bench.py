@@ -658,7 +658,6 @@ def main():
         tuned = gemm_tuning.enable()
 
     if args.blas != "default":
-        import torch
         torch.backends.cuda.preferred_blas_library("cublas" if args.blas == "rocblas" else "cublaslt")
 
     timer = EventTimer()
