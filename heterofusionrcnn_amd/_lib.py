@@ -56,6 +56,10 @@ _SIGNATURES = {
     "hf_bn_relu_fwd_train": [ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_bn_relu_fwd_eval": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "hf_bn_relu_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_bn_dropout_fwd_train": [ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _f, ctypes.c_ulonglong, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                _vp],
+    "hf_bn_dropout_bwd": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "hf_narrow_linear_dx": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp],
     "hf_bn_relu_fwd_train_ld": [ctypes.c_longlong, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _sz, _vp],
     "hf_bn_relu_bwd_ld": [ctypes.c_longlong, _i, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "hf_group_concat": [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

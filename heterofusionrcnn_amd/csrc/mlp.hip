@@ -103,6 +103,37 @@ __device__ __forceinline__ float elu_stream(float x, float &slope)
     return x > 0.0f ? x : e - 1.0f;
 }
 
+// Dropout fused into the normalisation (pointfly's dense -> dropout, pointcnn.py:371-384, rpn_model.py:556-568; tf.layers.dropout
+// keeps an element with probability 1 - rate and scales it by 1 / (1 - rate)).  The framework form is a pass of its own in each
+// direction (read, write, plus a mask tensor); here the keep decision is a counter hash of (seed of the call, element index),
+// evaluated in the apply pass and AGAIN in the two backward passes: no mask in memory, no extra pass.  16 random bits per element
+// (the rate is resolved to 1 / 65536); one 32-bit hash feeds two elements.
+struct BnDrop {
+    const unsigned long long *seed;   // device: the seed of this forward call (written by the statistics finalize kernel)
+    unsigned thresh;                  // keep iff bits >= thresh, thresh = round(rate * 65536)
+    float scale;                      // 1 / (1 - rate)
+};
+
+__device__ __forceinline__ unsigned mix32(unsigned h)   // a full-avalanche 32-bit finalizer (two multiplies)
+{
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+
+// multipliers (scale or 0) of the VEC elements of vector number vidx = row * cv + cvec
+template <int VEC>
+__device__ __forceinline__ void drop_multipliers(unsigned long long vidx, unsigned s0, unsigned s1, unsigned thresh, float scale, float (&m)[VEC])
+{
+    const unsigned h1 = mix32((static_cast<unsigned>(vidx) ^ s0) + mix32(static_cast<unsigned>(vidx >> 32) ^ s1));
+    m[0] = (h1 & 0xffffu) >= thresh ? scale : 0.0f;
+    if constexpr (VEC == 4) {
+        const unsigned h2 = mix32(h1 ^ 0x68bc21ebu);
+        m[1] = (h1 >> 16) >= thresh ? scale : 0.0f;
+        m[2] = (h2 & 0xffffu) >= thresh ? scale : 0.0f;
+        m[3] = (h2 >> 16) >= thresh ? scale : 0.0f;
+    }
+}
+
 // A thread's rows are rsub, rsub + rpb, ... < local (rows of the block); operands are addressed as a uniform block base plus a 32-bit
 // element offset (bn_geom keeps rows_per_block x row stride below 2^31).
 // partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over the block's rows
@@ -173,8 +204,21 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, 
                                                                 float momentum, float *__restrict__ running_mean,
                                                                 float *__restrict__ running_var,
                                                                 float *__restrict__ save_mean,
-                                                                float *__restrict__ save_invstd)
+                                                                float *__restrict__ save_invstd,
+                                                                unsigned long long *__restrict__ drop_state,
+                                                                unsigned long long *__restrict__ seed_out,
+                                                                unsigned long long salt)
 {
+    if (drop_state && blockIdx.x == 0 && threadIdx.x == 0) {
+        // one more forward call of this layer: its seed (splitmix64 of base seed, caller's salt and call number) for the apply pass
+        // that follows and for the backward passes
+        const unsigned long long calls = drop_state[1] + 1ull;
+        drop_state[1] = calls;
+        unsigned long long z = drop_state[0] + salt * 0xbf58476d1ce4e5b9ull + calls * 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        seed_out[0] = z ^ (z >> 31);
+    }
     const int ch = bn_finalize_channel();
     if (ch >= c) return;
     double s, q;
@@ -190,11 +234,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, 
 }
 
 // y = relu?(gamma*invstd*(x-mean) + beta)
-template <int VEC, bool ELU>
+template <int VEC, bool ELU, bool DROP>
 __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                 const float *__restrict__ x, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, const float *__restrict__ mean,
-                                const float *__restrict__ invstd, int relu, float *__restrict__ y, long long ldy)
+                                const float *__restrict__ invstd, int relu, float *__restrict__ y, long long ldy, BnDrop drop)
 {
     typedef typename VecT<VEC>::type V;
     const int t = threadIdx.x;
@@ -209,14 +253,19 @@ __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long lon
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    auto one = [&](const V &v) -> V {
+    unsigned ds0 = 0u, ds1 = 0u;
+    if (DROP) { const unsigned long long sd = *drop.seed; ds0 = static_cast<unsigned>(sd); ds1 = static_cast<unsigned>(sd >> 32); }
+    auto one = [&](const V &v, int row) -> V {
         V o;
+        float m[VEC];
+        if (DROP) drop_multipliers<VEC>(static_cast<unsigned long long>(r0 + row) * cv + cvec, ds0, ds1, drop.thresh, drop.scale, m);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float xv = vget<VEC>(v, i);
             if (ELU) xv = elu_stream(xv);
             float h = a[i] * (xv - mu[i]) + b[i];
             if (relu & kBnRelu) h = fmaxf(h, 0.0f);
+            if (DROP) h = h * m[i];
             vset<VEC>(o, i, h);
         }
         return o;
@@ -231,18 +280,18 @@ __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long lon
 #pragma unroll
         for (int u = 0; u < kBnUnroll; ++u) v[u] = ldv<VEC>(bx + ox + u * sx);
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) stv<VEC>(by + oy + u * sy, one(v[u]));
+        for (int u = 0; u < kBnUnroll; ++u) stv<VEC>(by + oy + u * sy, one(v[u], row + u * rpb));
     }
-    for (; row < local; row += rpb, ox += sx, oy += sy) stv<VEC>(by + oy, one(ldv<VEC>(bx + ox)));
+    for (; row < local; row += rpb, ox += sx, oy += sy) stv<VEC>(by + oy, one(ldv<VEC>(bx + ox), row));
 }
 
 // partial[blk][0][c] = sum dh, partial[blk][1][c] = sum dh*xhat  (dh = dy masked by the ReLU of a*x+b)
-template <int VEC, bool ELU>
+template <int VEC, bool ELU, bool DROP>
 __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                      const float *__restrict__ x, const float *__restrict__ dy,
                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                      const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                                     float *__restrict__ partial, long long lddy)
+                                     float *__restrict__ partial, long long lddy, BnDrop drop)
 {
     extern __shared__ float smem[];
     typedef typename VecT<VEC>::type V;
@@ -259,12 +308,17 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    auto add = [&](const V &v, const V &g) {
+    unsigned ds0 = 0u, ds1 = 0u;
+    if (DROP) { const unsigned long long sd = *drop.seed; ds0 = static_cast<unsigned>(sd); ds1 = static_cast<unsigned>(sd >> 32); }
+    auto add = [&](const V &v, const V &g, int row) {
+        float m[VEC];
+        if (DROP) drop_multipliers<VEC>(static_cast<unsigned long long>(r0 + row) * cv + cvec, ds0, ds1, drop.thresh, drop.scale, m);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float xv = vget<VEC>(v, i);
             if (ELU) xv = elu_stream(xv);
             float dh = vget<VEC>(g, i);
+            if (DROP) dh = dh * m[i];
             if ((relu & kBnRelu) && !(a[i] * (xv - mu[i]) + b[i] > 0.0f)) dh = 0.0f;
             s1[i] += dh;
             s2[i] += dh * ((xv - mu[i]) * is[i]);
@@ -279,9 +333,9 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
 #pragma unroll
         for (int u = 0; u < kBnUnroll; ++u) { v[u] = ldv<VEC>(bx + ox + u * sx); g[u] = ldv<VEC>(bg + og + u * sg); }
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) add(v[u], g[u]);
+        for (int u = 0; u < kBnUnroll; ++u) add(v[u], g[u], row + u * rpb);
     }
-    for (; row < local; row += rpb, ox += sx, og += sg) add(ldv<VEC>(bx + ox), ldv<VEC>(bg + og));
+    for (; row < local; row += rpb, ox += sx, og += sg) add(ldv<VEC>(bx + ox), ldv<VEC>(bg + og), row);
     reduce_rows<VEC>(s1, s2, cv, rpb, cvec, rsub, smem);
     if (rsub == 0) {
 #pragma unroll
@@ -305,13 +359,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int c, int nblk, c
 }
 
 // dx = gamma*invstd*(dh - dbeta/R - xhat*dgamma/R)
-template <int VEC, bool ELU>
+template <int VEC, bool ELU, bool DROP>
 __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                  const float *__restrict__ x, const float *__restrict__ dy,
                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                  const float *__restrict__ mean, const float *__restrict__ invstd,
                                  const float *__restrict__ dgamma, const float *__restrict__ dbeta, int relu,
-                                 float *__restrict__ dx, float *__restrict__ colsum_partial, long long lddy)
+                                 float *__restrict__ dx, float *__restrict__ colsum_partial, long long lddy, BnDrop drop)
 {
     extern __shared__ float smem[];
     typedef typename VecT<VEC>::type V;
@@ -331,14 +385,19 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
     }
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    auto one = [&](const V &v, const V &g) -> V {
+    unsigned ds0 = 0u, ds1 = 0u;
+    if (DROP) { const unsigned long long sd = *drop.seed; ds0 = static_cast<unsigned>(sd); ds1 = static_cast<unsigned>(sd >> 32); }
+    auto one = [&](const V &v, const V &g, int row) -> V {
         V o;
+        float m[VEC];
+        if (DROP) drop_multipliers<VEC>(static_cast<unsigned long long>(r0 + row) * cv + cvec, ds0, ds1, drop.thresh, drop.scale, m);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float slope = 1.0f;
             float xv = vget<VEC>(v, i);
             if (ELU) xv = elu_stream(xv, slope);
             float dh = vget<VEC>(g, i);
+            if (DROP) dh = dh * m[i];
             if ((relu & kBnRelu) && !(a[i] * (xv - mu[i]) + b[i] > 0.0f)) dh = 0.0f;
             const float xhat = (xv - mu[i]) * is[i];
             float d = a[i] * (dh - c1[i] - xhat * c2[i]);
@@ -358,9 +417,9 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
 #pragma unroll
         for (int u = 0; u < kBnUnroll; ++u) { v[u] = ldv<VEC>(bx + ox + u * sx); g[u] = ldv<VEC>(bg + og + u * sg); }
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) stv<VEC>(bo + ox + u * sx, one(v[u], g[u]));
+        for (int u = 0; u < kBnUnroll; ++u) stv<VEC>(bo + ox + u * sx, one(v[u], g[u], row + u * rpb));
     }
-    for (; row < local; row += rpb, ox += sx, og += sg) stv<VEC>(bo + ox, one(ldv<VEC>(bx + ox), ldv<VEC>(bg + og)));
+    for (; row < local; row += rpb, ox += sx, og += sg) stv<VEC>(bo + ox, one(ldv<VEC>(bx + ox), ldv<VEC>(bg + og), row));
     if (colsum_partial) {  // column sums of dx = the bias gradient of the Linear that produced x
         reduce_rows<VEC>(cs, unused, cv, rpb, cvec, rsub, smem);
         if (rsub == 0) {
@@ -748,7 +807,7 @@ void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *part
                               float *running_mean, float *running_var, float *save_mean, float *save_invstd, hipStream_t st)
 {
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, nblk, partial, eps, momentum,
-                       running_mean, running_var, save_mean, save_invstd);
+                       running_mean, running_var, save_mean, save_invstd, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), 0ull);
 }
 
 void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma, float *dbeta, hipStream_t st)
@@ -756,47 +815,112 @@ void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, nblk, partial, dgamma, dbeta);
 }
 
-// the streaming passes by vector width and activation-on-load
-template <typename F4E, typename F4, typename F1E, typename F1>
-static void bn_dispatch(const BnGeom &g, bool elu, F4E f4e, F4 f4, F1E f1e, F1 f1)
+// dx (rows, cin) = g (rows, cout) W (cout, cin) for a HANDFUL of outputs (the segmentation head, rpn_model.py: 256 -> classes + 1).
+// As a GEMM its inner dimension is cout <= 4 (the library: 490 us at 131 072 rows); as scaled additions in the framework it was
+// cout passes over dx.  Here: one pass, a thread owns VEC channels (its cout x VEC weights in registers) and strides over rows.
+constexpr int kNarrowMaxOut = 4;
+template <int VEC>
+__global__ void narrow_linear_dx_kernel(long long rows, int cin, int cout, int cv, int rpb, long long rows_per_block,
+                                        const float *__restrict__ g, const float *__restrict__ w, float *__restrict__ dx)
 {
-    if (g.vec == 4) { if (elu) f4e(); else f4(); }
-    else { if (elu) f1e(); else f1(); }
+    typedef typename VecT<VEC>::type V;
+    const int t = threadIdx.x;
+    const int cvec = t % cv, rsub = t / cv;
+    float wr[kNarrowMaxOut][VEC];
+#pragma unroll
+    for (int j = 0; j < kNarrowMaxOut; ++j)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) wr[j][i] = j < cout ? w[static_cast<size_t>(j) * cin + cvec * VEC + i] : 0.0f;
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (long long r = r0 + rsub; r < r1; r += rpb) {
+        float gv[kNarrowMaxOut];
+#pragma unroll
+        for (int j = 0; j < kNarrowMaxOut; ++j) gv[j] = j < cout ? g[r * cout + j] : 0.0f;
+        V o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            // the framework's order: g_0 w_0, then + g_j w_j for j = 1 .. cout-1
+            float acc = gv[0] * wr[0][i];
+#pragma unroll
+            for (int j = 1; j < kNarrowMaxOut; ++j)
+                if (j < cout) acc = acc + gv[j] * wr[j][i];
+            vset<VEC>(o, i, acc);
+        }
+        stv<VEC>(dx + r * cin + cvec * VEC, o);
+    }
 }
+
+// the streaming passes by vector width, activation-on-load and fused dropout (drop == nullptr: none)
+template <template <int, bool, bool> class L, typename... A>
+static void bn_dispatch(const BnGeom &g, bool elu, bool drop, A... a)
+{
+    if (g.vec == 4) {
+        if (elu) { if (drop) L<4, true, true>::go(a...); else L<4, true, false>::go(a...); }
+        else { if (drop) L<4, false, true>::go(a...); else L<4, false, false>::go(a...); }
+    } else {
+        if (elu) { if (drop) L<1, true, true>::go(a...); else L<1, true, false>::go(a...); }
+        else { if (drop) L<1, false, true>::go(a...); else L<1, false, false>::go(a...); }
+    }
+}
+
+static const BnDrop kNoDrop = { nullptr, 0u, 1.0f };
 
 static void launch_bn_stats(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, float *partial, bool elu)
 {
     const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-#define HF_BN_L(V, E) [&] { hipLaunchKernelGGL((bn_stats_kernel<V, E>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, partial); }
-    bn_dispatch(g, elu, HF_BN_L(4, true), HF_BN_L(4, false), HF_BN_L(1, true), HF_BN_L(1, false));
+#define HF_BN_L(V, E) hipLaunchKernelGGL((bn_stats_kernel<V, E>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, partial)
+    if (g.vec == 4) { if (elu) HF_BN_L(4, true); else HF_BN_L(4, false); }
+    else { if (elu) HF_BN_L(1, true); else HF_BN_L(1, false); }
 #undef HF_BN_L
 }
 
+template <int V, bool E, bool D> struct BnApplyL {
+    static void go(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *gamma, const float *beta,
+                   const float *mean, const float *invstd, int relu, float *y, long long ldy, BnDrop drop)
+    {
+        hipLaunchKernelGGL((bn_apply_kernel<V, E, D>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, gamma,
+                           beta, mean, invstd, relu, y, ldy, drop);
+    }
+};
 static void launch_bn_apply(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *gamma, const float *beta,
-                            const float *mean, const float *invstd, int relu, float *y, long long ldy)
+                            const float *mean, const float *invstd, int relu, float *y, long long ldy, BnDrop drop = kNoDrop)
 {
-#define HF_BN_L(V, E) [&] { hipLaunchKernelGGL((bn_apply_kernel<V, E>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, gamma, beta, mean, invstd, relu, y, ldy); }
-    bn_dispatch(g, (relu & kBnEluIn) != 0, HF_BN_L(4, true), HF_BN_L(4, false), HF_BN_L(1, true), HF_BN_L(1, false));
-#undef HF_BN_L
+    bn_dispatch<BnApplyL>(g, (relu & kBnEluIn) != 0, drop.seed != nullptr, g, st, rows, c, x, gamma, beta, mean, invstd, relu, y, ldy, drop);
 }
 
+template <int V, bool E, bool D> struct BnReduceL {
+    static void go(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
+                   const float *beta, const float *mean, const float *invstd, int relu, float *partial, long long lddy, BnDrop drop)
+    {
+        const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, E, D>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy,
+                           gamma, beta, mean, invstd, relu, partial, lddy, drop);
+    }
+};
 static void launch_bn_bwd_reduce(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
-                                 const float *beta, const float *mean, const float *invstd, int relu, float *partial, long long lddy)
+                                 const float *beta, const float *mean, const float *invstd, int relu, float *partial, long long lddy,
+                                 BnDrop drop = kNoDrop)
 {
-    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-#define HF_BN_L(V, E) [&] { hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, E>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy, gamma, beta, mean, invstd, relu, partial, lddy); }
-    bn_dispatch(g, (relu & kBnEluIn) != 0, HF_BN_L(4, true), HF_BN_L(4, false), HF_BN_L(1, true), HF_BN_L(1, false));
-#undef HF_BN_L
+    bn_dispatch<BnReduceL>(g, (relu & kBnEluIn) != 0, drop.seed != nullptr, g, st, rows, c, x, dy, gamma, beta, mean, invstd, relu, partial, lddy, drop);
 }
 
+template <int V, bool E, bool D> struct BnDxL {
+    static void go(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
+                   const float *beta, const float *mean, const float *invstd, const float *dgamma, const float *dbeta, int relu, float *dx,
+                   float *colsum_partial, long long lddy, BnDrop drop)
+    {
+        const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<V, E, D>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy,
+                           gamma, beta, mean, invstd, dgamma, dbeta, relu, dx, colsum_partial, lddy, drop);
+    }
+};
 static void launch_bn_bwd_dx(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
                              const float *beta, const float *mean, const float *invstd, const float *dgamma, const float *dbeta, int relu,
-                             float *dx, float *colsum_partial, long long lddy)
+                             float *dx, float *colsum_partial, long long lddy, BnDrop drop = kNoDrop)
 {
-    const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-#define HF_BN_L(V, E) [&] { hipLaunchKernelGGL((bn_bwd_dx_kernel<V, E>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy, gamma, beta, mean, invstd, dgamma, dbeta, relu, dx, colsum_partial, lddy); }
-    bn_dispatch(g, (relu & kBnEluIn) != 0, HF_BN_L(4, true), HF_BN_L(4, false), HF_BN_L(1, true), HF_BN_L(1, false));
-#undef HF_BN_L
+    bn_dispatch<BnDxL>(g, (relu & kBnEluIn) != 0, drop.seed != nullptr, g, st, rows, c, x, dy, gamma, beta, mean, invstd, dgamma, dbeta, relu, dx,
+                       colsum_partial, lddy, drop);
 }
 
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
@@ -839,7 +963,7 @@ HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const 
     float *partial = static_cast<float *>(workspace);
     launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
-                       momentum, running_mean, running_var, save_mean, save_invstd);
+                       momentum, running_mean, running_var, save_mean, save_invstd, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), 0ull);
     launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
     return launch_status();
 }
@@ -916,6 +1040,69 @@ HF_API int hf_bn_relu_bwd(long long rows, int c, const float *x, const float *dy
                              workspace_bytes, stream);
 }
 
+static bool drop_args(float rate, BnDrop &d, const unsigned long long *seed)
+{
+    if (!(rate >= 0.0f) || !(rate < 1.0f) || !seed) return false;
+    d.seed = seed;
+    d.thresh = static_cast<unsigned>(rate * 65536.0f + 0.5f);
+    if (d.thresh > 65535u) d.thresh = 65535u;
+    d.scale = 1.0f / (1.0f - rate);
+    return true;
+}
+
+HF_API int hf_bn_dropout_fwd_train(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                                   float *running_mean, float *running_var, int relu, float rate, unsigned long long salt,
+                                   unsigned long long *drop_state, unsigned long long *seed_out, float *y, float *save_mean,
+                                   float *save_invstd, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows <= 0 || c <= 0 || c > 4096 || !x || !gamma || !beta || !y || !save_mean || !save_invstd || !drop_state || !seed_out) return HF_EINVAL;
+    BnDrop d;
+    if (!drop_args(rate, d, seed_out)) return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !(aligned16(x) && aligned16(y))) return HF_EINVAL;
+    if (!bn_offsets_fit(g, c)) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
+                       momentum, running_mean, running_var, save_mean, save_invstd, drop_state, seed_out, salt);
+    launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, static_cast<long long>(c), d);
+    return launch_status();
+}
+
+HF_API int hf_bn_dropout_bwd(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
+                             const float *save_mean, const float *save_invstd, int relu, float rate, const unsigned long long *seed,
+                             float *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream)
+{
+    if (rows <= 0 || c <= 0 || c > 4096 || !x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta) return HF_EINVAL;
+    BnDrop d;
+    if (!drop_args(rate, d, seed)) return HF_EINVAL;
+    if (!workspace || workspace_bytes < hf_bn_workspace(rows, c)) return HF_EWORKSPACE;
+    BnGeom g = bn_geom(rows, c);
+    if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx))) return HF_EINVAL;
+    if (!bn_offsets_fit(g, c)) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    launch_bn_bwd_reduce(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, static_cast<long long>(c), d);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
+    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, nullptr, static_cast<long long>(c), d);
+    return launch_status();
+}
+
+HF_API int hf_narrow_linear_dx(long long rows, int cin, int cout, const float *g, const float *w, float *dx, hf_stream_t stream)
+{
+    if (rows <= 0 || cin <= 0 || cin > 4096 || cout <= 0 || cout > kNarrowMaxOut || !g || !w || !dx) return HF_EINVAL;
+    BnGeom gm = bn_geom(rows, cin);
+    if (gm.vec == 4 && !aligned16(dx)) return HF_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (gm.vec == 4)
+        hipLaunchKernelGGL((narrow_linear_dx_kernel<4>), dim3(gm.nblk), dim3(gm.threads), 0, st, rows, cin, cout, gm.cv, gm.rpb, gm.rows_per_block, g, w, dx);
+    else
+        hipLaunchKernelGGL((narrow_linear_dx_kernel<1>), dim3(gm.nblk), dim3(gm.threads), 0, st, rows, cin, cout, gm.cv, gm.rpb, gm.rows_per_block, g, w, dx);
+    return launch_status();
+}
+
 HF_API int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
                              const float *save_mean, const float *save_invstd, const float *dgamma, const float *dbeta,
                              int relu, float *dx, hf_stream_t stream)
@@ -947,7 +1134,7 @@ HF_API int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z
         float *partial = static_cast<float *>(workspace);
         launch_bn_stats(g, st, rows, c, z, partial, false);
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps, momentum,
-                           running_mean, running_var, mean, invstd);
+                           running_mean, running_var, mean, invstd, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), 0ull);
     }
     BnGeom gg = bn_geom(groups, c);
     if (gg.vec == 4 && !aligned16(z)) return HF_EINVAL;

@@ -27,6 +27,20 @@ def _workspace(rows, c, device):
 _STATS_GENERATION = [0]
 
 
+_DROP_LAYERS = [0]      # BatchNormReLU modules built so far in this process (distinct dropout seeds per layer)
+
+
+DROPOUT_SALT = None     # tests: a fixed salt instead of the rank (to reproduce another rank's masks in one process)
+
+
+def _dropout_salt():
+    """mixed into the dropout seeds: ranks share every buffer after the parameter broadcast, their masks must still differ"""
+    if DROPOUT_SALT is not None:
+        return int(DROPOUT_SALT)
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def running_stats_written():
     _STATS_GENERATION[0] += 1
 
@@ -60,6 +74,40 @@ class _BNReLUTrain(torch.autograd.Function):
                                         ctx.relu, ptr(dx), ptr(dgamma), ptr(dbeta), None, ptr(ws), nbytes,
                                         stream_ptr()), "bn_relu_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class _BNDropoutTrain(torch.autograd.Function):
+    """dropout(bn(act(x))) as ONE node: the keep decisions are recomputed from a per-call seed in the backward passes
+    (hf_bn_dropout_fwd_train / _bwd): no mask tensor, no dropout pass in either direction"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, rate, drop_state, salt):
+        running_stats_written()
+        rows, c = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
+        seed = torch.empty((1,), dtype=torch.int64, device=x.device)
+        ws, nbytes = _workspace(rows, c, x.device)
+        check(_lib.lib().hf_bn_dropout_fwd_train(rows, c, ptr(x), ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var),
+                                                 int(relu), float(rate), int(salt), ptr(drop_state), ptr(seed), ptr(y), ptr(mean), ptr(invstd),
+                                                 ptr(ws), nbytes, stream_ptr()), "bn_dropout_fwd_train")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, seed)
+        ctx.relu, ctx.rate = int(relu), float(rate)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd, seed = ctx.saved_tensors
+        rows, c = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        ws, nbytes = _workspace(rows, c, x.device)
+        check(_lib.lib().hf_bn_dropout_bwd(rows, c, ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ctx.relu, ctx.rate,
+                                           ptr(seed), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream_ptr()), "bn_dropout_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def _splitk_wgrad(g, x, chunk=None):
@@ -127,7 +175,7 @@ def _zeros(n, device):
 class _NarrowLinear(torch.autograd.Function):
     """y = x W^T + b for a handful of outputs (the segmentation head: 256 -> 2).  The input gradient g W is a GEMM with
     an inner dimension of 2, which the library runs at 490 us for 131 072 rows; written as Cout scaled additions it is
-    one streaming pass.  Weight gradient on the split-K path."""
+    one streaming pass (hf_narrow_linear_dx).  Weight gradient on the split-K path."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -140,9 +188,9 @@ class _NarrowLinear(torch.autograd.Function):
         g = g.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = g[:, 0:1] * weight[0]
-            for j in range(1, weight.shape[0]):
-                dx = torch.addcmul(dx, g[:, j:j + 1], weight[j])
+            dx = torch.empty_like(x)
+            check(_lib.lib().hf_narrow_linear_dx(x.shape[0], x.shape[1], weight.shape[0], ptr(g), ptr(weight.contiguous()), ptr(dx),
+                                                 stream_ptr()), "narrow_linear_dx")
         dw = _splitk_wgrad(g, x) if ctx.needs_input_grad[1] else None
         db = g.sum(0) if ctx.needs_input_grad[2] else None
         return dx, dw, db
@@ -608,6 +656,12 @@ class BatchNormReLU(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self._eval_invstd = None      # (key, 1/sqrt(running_var + eps)): inference reuses it
+        # fused dropout (forward(x, dropout=rate)): [base seed, forward calls so far], advanced on the device by the kernels.  The
+        # base seed follows torch.manual_seed and the order in which layers are built (no draw from the generator: the initial
+        # weights stay what they were); not part of the state dict.
+        _DROP_LAYERS[0] += 1
+        base = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_LAYERS[0] * 0xBF58476D1CE4E5B9) % (1 << 62)
+        self.register_buffer("drop_state", torch.tensor([base, 0], dtype=torch.int64), persistent=False)
 
     def train(self, mode=True):
         self._eval_invstd = None
@@ -626,11 +680,16 @@ class BatchNormReLU(nn.Module):
             self._eval_invstd = (key, torch.rsqrt(rv + self.eps))
         return self._eval_invstd[1]
 
-    def forward(self, x):
+    def forward(self, x, dropout=0.0):
+        """dropout (a rate): training mode applies tf.layers.dropout(rate) to the output inside the normalisation pass (no pass of its
+        own, no mask tensor); inference ignores it, as dropout does"""
         assert x.dim() == 2 and x.shape[1] == self.num_features
         if not x.is_cuda:
             raise RuntimeError("BatchNormReLU: heterofusionrcnn_amd has no CPU implementation")
         x = x.contiguous()
+        if self.training and dropout > 0.0:
+            return _BNDropoutTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
+                                         (1 if self.relu else 0) | (2 if self.elu_in else 0), dropout, self.drop_state, _dropout_salt())
         if self.training:
             return _BNReLUTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                       self.momentum, (1 if self.relu else 0) | (2 if self.elu_in else 0))

@@ -46,9 +46,9 @@ class EluBN(nn.Module):
         self.bn = BatchNormReLU(channels, eps=1e-3, momentum=0.01, relu=False, elu_in=activation)
         self.activation = activation
 
-    def forward(self, x):
+    def forward(self, x, dropout=0.0):
         shape = x.shape
-        return self.bn(x.reshape(-1, shape[-1])).reshape(shape)
+        return self.bn(x.reshape(-1, shape[-1]), dropout).reshape(shape)
 
 
 class Dense(nn.Module):
@@ -60,8 +60,9 @@ class Dense(nn.Module):
         nn.init.xavier_normal_(self.linear.weight)
         self.post = EluBN(cout, activation)
 
-    def forward(self, x):
-        return self.post(linear_nobias(x, self.linear.weight))
+    def forward(self, x, dropout=0.0):
+        """dropout: the rate of the tf.layers.dropout that follows this layer (training mode: fused into its BatchNorm)"""
+        return self.post(linear_nobias(x, self.linear.weight), dropout)
 
 
 class _DenseChainElu(torch.autograd.Function):
@@ -747,5 +748,5 @@ class PointCnnBackbone(nn.Module):
             cur = self.fuse[li](x)                                   # x = [x-deconv | encoder features of the query layer]
         out = cur if cur is not None else fts[-1]        # no decoder (the RCNN's extractor): the last encoder layer
         for layer, rate in zip(self.fc, self.fc_drop):
-            out = F.dropout(layer(out), p=rate, training=self.training)                                   # :371-384
+            out = layer(out, dropout=rate if self.training else 0.0)                                      # dense -> dropout, :371-384
         return out

@@ -120,7 +120,7 @@ class _FcStack(nn.Module):
 
     def forward(self, x):
         for layer, rate in zip(self.layers, self.rates):
-            x = F.dropout(layer(x), p=rate, training=self.training)
+            x = layer(x, dropout=rate if self.training else 0.0)
         return x
 
 

@@ -258,8 +258,9 @@ class DenseEluBN(nn.Module):
         self.bn = BatchNormReLU(cout, eps=1e-3, momentum=0.01, relu=False, elu_in=activation)
         self.activation = activation
 
-    def forward(self, x):
-        return self.bn(linear_nobias(x, self.linear.weight))
+    def forward(self, x, dropout=0.0):
+        """dropout: the rate of the tf.layers.dropout that follows this layer (training mode: fused into the BatchNorm passes)"""
+        return self.bn(linear_nobias(x, self.linear.weight), dropout)
 
 
 class RpnHeads(nn.Module):
@@ -292,7 +293,7 @@ class RpnHeads(nn.Module):
         x = x.reshape(b * p, -1)
         fused = x
         for layer, rate in zip(self.fc, self.drop):
-            x = F.dropout(layer(x), p=rate, training=self.training)     # tf.layers.dropout(rate)
+            x = layer(x, dropout=rate if self.training else 0.0)       # dense -> tf.layers.dropout(rate), fused into the BatchNorm
         out = self.out(x).reshape(b, p, self.cfg.num_classes, self.cfg.head_width)
         return (seg_logits, out, fused.reshape(b, p, -1)) if return_fused else (seg_logits, out)
 

@@ -380,6 +380,26 @@ int hf_lift_elu_bn_bwd(long long rows, int c0, int c1, const float *x3, const fl
                        const float *mean0, const float *invstd0, const float *dz1, const float *w1_t, float *grad_w0_t,
                        float *grad_w1, float *dgamma0, float *dbeta0, void *workspace, size_t workspace_bytes, hf_stream_t stream);
 
+/* BatchNorm (training mode) with the DROPOUT that follows it fused in -- pointfly's dense -> dropout of the PointCNN fc layers and of
+ * the RPN box head (hf/core/feature_extractors/pointcnn.py:371-384, hf/core/models/rpn_model.py:556-568: tf.layers.dropout keeps an
+ * element with probability 1 - rate and scales it by 1 / (1 - rate)).  y = dropout(bn(act(x))).  The keep decision of an element
+ * is a counter hash of (seed of the call, element index), evaluated in the apply pass and again in the two backward passes: no
+ * mask tensor, no pass of its own in either direction.  drop_state (device, two 64-bit words: base seed, forward calls so far) belongs
+ * to the layer and is advanced on the device (so a captured step draws new masks at every replay); seed_out (device, one word)
+ * receives this call's seed and is what hf_bn_dropout_bwd takes.  salt: mixed into the seed (the caller's rank: ranks share the
+ * base seed after the parameter broadcast).  0 <= rate < 1, resolved to 1 / 65536.  Other arguments as hf_bn_relu_fwd_train / _bwd. */
+int hf_bn_dropout_fwd_train(long long rows, int c, const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                            float *running_mean, float *running_var, int relu, float rate, unsigned long long salt,
+                            unsigned long long *drop_state, unsigned long long *seed_out, float *y, float *save_mean,
+                            float *save_invstd, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+int hf_bn_dropout_bwd(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
+                      const float *save_mean, const float *save_invstd, int relu, float rate, const unsigned long long *seed,
+                      float *dx, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, hf_stream_t stream);
+
+/* Input gradient of a Linear with a handful of outputs (the segmentation head of the RPN, hf/core/models/rpn_model.py: dense to
+ * classes + 1 logits): dx (rows, cin) = g (rows, cout) w (cout, cin), cout <= 4, one streaming pass. */
+int hf_narrow_linear_dx(long long rows, int cin, int cout, const float *g, const float *w, float *dx, hf_stream_t stream);
+
 /* The second half of hf_bn_relu_bwd alone: dx from dy, x and ALREADY KNOWN dgamma / dbeta (no reduction pass). */
 int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float *dy, const float *gamma, const float *beta,
                       const float *save_mean, const float *save_invstd, const float *dgamma, const float *dbeta, int relu,

@@ -54,6 +54,11 @@ def loss_of(net, core, b, r, geometry=None):
     """the scalar the step differentiates; the dropout masks of shard r are fixed by the seed"""
     torch.manual_seed(1000 + r)
     torch.cuda.manual_seed(1000 + r)
+    # the dropout fused into the BatchNorm passes draws from each layer's own device state and the rank: pin both to the shard
+    from heterofusionrcnn_amd import mlp as mlp_mod
+    mlp_mod.DROPOUT_SALT = r
+    for i, mod in enumerate(m for m in core.modules() if isinstance(m, mlp_mod.BatchNormReLU)):
+        mod.drop_state.copy_(torch.tensor([77000 + 13 * i, 0], dtype=torch.int64))
     if WORKLOAD == "rpn_multiclass":
         xyz, inten, lc, lr = b
         seg_logits, head = net(xyz, inten, geometry=geometry)

@@ -164,3 +164,21 @@ def test_xconv_gather_and_elu_chain_argument_checks():
     assert L.hf_linear_elu_bn_bwd(1024, 64, 64, one, one, one, None, one, one, one, one, one, one, one, 1 << 20, None) == _lib.HF_EINVAL
     assert L.hf_linear_elu_bn_fwd(1024, 3, 512, one, None, None, None, None, None, one, one, 1e-3, 0.01, None, None, one, one, one, 1 << 20,
                                   None) == _lib.HF_EINVAL                                                                       # cout <= 256
+
+
+def test_bn_dropout_and_narrow_linear_argument_checks():
+    """round-4 entry points: dropout fused into the BatchNorm passes, the input gradient of the narrow (segmentation) head"""
+    from heterofusionrcnn_amd import _lib
+    L = _lib.lib()
+    one = ctypes.c_void_p(16)
+    big = 1 << 24
+    fwd = lambda rate, state=one, seed=one, wsb=big: L.hf_bn_dropout_fwd_train(4096, 64, one, one, one, 1e-3, 0.01, None, None, 2, rate, 0, state,
+                                                                               seed, one, one, one, one, wsb, None)
+    assert fwd(1.0) == _lib.HF_EINVAL and fwd(-0.1) == _lib.HF_EINVAL and fwd(float("nan")) == _lib.HF_EINVAL      # 0 <= rate < 1
+    assert fwd(0.5, state=None) == _lib.HF_EINVAL and fwd(0.5, seed=None) == _lib.HF_EINVAL                       # the layer's state / the call's seed
+    assert fwd(0.5, wsb=16) == _lib.HF_EWORKSPACE
+    bwd = lambda rate, seed=one, wsb=big: L.hf_bn_dropout_bwd(4096, 64, one, one, one, one, one, one, 2, rate, seed, one, one, one, one, wsb, None)
+    assert bwd(1.0) == _lib.HF_EINVAL and bwd(0.5, seed=None) == _lib.HF_EINVAL and bwd(0.5, wsb=16) == _lib.HF_EWORKSPACE
+    assert L.hf_narrow_linear_dx(4096, 256, 5, one, one, one, None) == _lib.HF_EINVAL                               # at most four outputs
+    assert L.hf_narrow_linear_dx(4096, 256, 2, one, None, one, None) == _lib.HF_EINVAL
+    assert L.hf_narrow_linear_dx(0, 256, 2, one, one, one, None) == _lib.HF_EINVAL

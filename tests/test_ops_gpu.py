@@ -1619,6 +1619,81 @@ def test_bn_with_elu_on_load(hf, rows, c):
     assert torch.allclose(ye.double(), refe, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("rows,c,mode,rate", [(20000, 64, 2, 0.5), (5000, 256, 2, 0.3), (9000, 76, 1, 0.5), (3001, 7, 2, 0.25)])
+def test_bn_with_fused_dropout(hf, rows, c, mode, rate):
+    """BatchNormReLU(x, dropout=rate) = tf.layers.dropout(rate)(bn(act(x))) of pointfly's dense -> dropout (pointcnn.py:371-384,
+    rpn_model.py:556-568) as one node.  The mask of a call depends on (layer seed, call number, element index) only, so it is read
+    back by repeating the call from the same state with gamma = 0, beta = 1 (output = mask / (1 - rate)); then: output and all
+    gradients against torch in fp64 with THAT mask, keep fraction, a second call draws another mask, eval mode ignores the rate."""
+    from heterofusionrcnn_amd.mlp import BatchNormReLU
+    g = torch.Generator().manual_seed(rows + c)
+    x = torch.randn(rows, c, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(rows, c, generator=g).cuda()
+    bn = BatchNormReLU(c, eps=1e-3, momentum=0.01, relu=bool(mode & 1), elu_in=bool(mode & 2)).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5); bn.bias.copy_(torch.randn(c, generator=g))
+    state0 = bn.drop_state.clone()
+    y = bn(x, dropout=rate)
+    y.backward(dy)
+    running_mean = bn.running_mean.clone()
+    assert int(bn.drop_state[1]) == int(state0[1]) + 1 and int(bn.drop_state[0]) == int(state0[0])
+    with torch.no_grad():
+        w0, b0 = bn.weight.clone(), bn.bias.clone()
+        bn.weight.zero_(); bn.bias.fill_(1.0)
+        bn.drop_state.copy_(state0)
+        mask = bn(x.detach(), dropout=rate).double()          # 0 or 1 / (1 - rate)
+        bn.weight.copy_(w0); bn.bias.copy_(b0)
+    keep = mask > 0
+    assert torch.allclose(mask[keep], torch.full_like(mask[keep], 1.0 / (1.0 - rate)), rtol=1e-6)
+    frac, n = keep.double().mean().item(), keep.numel()
+    assert abs(frac - (1.0 - rate)) < 5.0 * (rate * (1.0 - rate) / n) ** 0.5 + 2.0 / 65536, frac
+    # rows and columns are both mixed: no column or row is all kept / all dropped
+    assert 0 < keep.double().mean(0).min() and keep.double().mean(0).max() < 1
+    xr = x.detach().double().requires_grad_(True)
+    w, b = w0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    e = torch.nn.functional.elu(xr) if mode & 2 else xr
+    mean, var = e.mean(0), e.var(0, unbiased=False)
+    full = (e - mean) / torch.sqrt(var + 1e-3) * w + b
+    if mode & 1:
+        full = torch.relu(full)
+    ref = full * mask
+    ref.backward(dy.double())
+    assert torch.allclose(y.double(), ref.detach(), rtol=1e-4, atol=2e-4)
+    assert (y.detach()[~keep] == 0).all()
+    assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-3, atol=1e-3 * xr.grad.abs().max().item())
+    assert torch.allclose(bn.weight.grad.double(), w.grad, rtol=1e-3, atol=1e-3 * (1 + w.grad.abs().max().item()))
+    assert torch.allclose(bn.bias.grad.double(), b.grad, rtol=1e-3, atol=1e-3 * (1 + b.grad.abs().max().item()))
+    # the statistics are those of the undropped activation
+    assert torch.allclose(running_mean.double(), 0.01 * mean.detach(), rtol=1e-3, atol=1e-5)
+    # another call, another mask (the call counter lives on the device)
+    y2 = bn(x.detach(), dropout=rate)
+    differ = ((y2 != 0) != keep).double().mean().item()
+    assert abs(differ - 2 * rate * (1 - rate)) < 0.05, differ
+    bn.eval()
+    ye = bn(x.detach(), dropout=rate)
+    bn_ref = (e.detach() - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + 1e-3) * w.detach() + b.detach()
+    assert torch.allclose(ye.double(), torch.relu(bn_ref) if mode & 1 else bn_ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(20000, 256, 4), (4099, 76, 2), (3000, 7, 3), (131072, 256, 4)])
+def test_narrow_linear_input_gradient(hf, rows, cin, cout):
+    """hf_narrow_linear_dx (the segmentation head's input gradient, one pass) against g @ W; through mlp.linear_narrow's autograd node"""
+    from heterofusionrcnn_amd.mlp import linear_narrow
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(cout, cin, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(cout, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(rows, cout, generator=g).cuda()
+    y = linear_narrow(x, w, b)
+    y.backward(dy)
+    xr, wr, br = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    torch.nn.functional.linear(xr, wr, br).backward(dy.double())
+    assert torch.allclose(y.double(), torch.nn.functional.linear(xr, wr, br), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(w.grad.double(), wr.grad, rtol=1e-3, atol=1e-2)
+    assert torch.allclose(b.grad.double(), br.grad, rtol=1e-4, atol=1e-2)
+
+
 def test_knn_point_against_three_term_formula(hf, oracle_mod):
     """knn_point (exact (q-p)^2, ties to the lower index) against the reference's expression restated as written
     (tf_grouping.py:80-92: |q|^2 - 2 q.p^T + |p|^2, top_k): the neighbour SETS must agree wherever the gap between the
