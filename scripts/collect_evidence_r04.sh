@@ -21,4 +21,13 @@ python scripts/parse_trace.py $OUT/prof_roofline qbp_cell > $OUT/roofline_kernel
 BQ_SHAPES=0,1,2,3,7,4,5 timeout -k 10 200 python3 scripts/probes/bq_sorted_timing.py 2>/dev/null | grep "^[0-9]" > $OUT/bq_sorted_timing.txt; cat $OUT/bq_sorted_timing.txt | cut -c1-250
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_two_stage -o two_stage -- python3 scripts/two_stage_profile.py > $OUT/two_stage.log 2>&1; echo "rocprof two-stage exit $?"; tail -1 $OUT/two_stage.log
 timeout -k 10 200 python scripts/bev_nms_timing.py > $OUT/bev_nms_timing.json 2>&1; echo "bev_nms_timing exit $?"; tail -3 $OUT/bev_nms_timing.json
+# bev_iou ALU-bound fraction (stamped with the hash of bev_iou.hip; bench.py prints it only while the stamp matches)
+rm -rf $OUT/bev_pmc $OUT/bev_tr
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/bev_pmc -o p -- python3 scripts/bev_nms_kernels.py > /dev/null 2>&1 && \
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/bev_tr -o t -- python3 scripts/bev_nms_kernels.py > /dev/null 2>&1; echo "bev alu passes exit $?"
+python3 scripts/make_alu_json.py $OUT/bev_pmc $OUT/bev_tr $OUT/bev_iou_alu.json
+# one frame per GPU: kernel stats of the replayed step
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_f1 -o f1 -- python3 bench.py --frames-per-gpu 1 --steps 16 --warmup 3 --no-cpu-baseline --no-op-table --no-side-runs > $OUT/prof_f1.log 2>&1; echo "rocprof f1 exit $?"
+python scripts/probes/step_breakdown.py $(find $OUT/prof_bench -name "*kernel_trace.csv" | head -1) > $OUT/step_breakdown.txt 2>&1; head -3 $OUT/step_breakdown.txt
+rm -rf $OUT/bev_pmc/*/*agent_info.csv
 echo done
