@@ -177,23 +177,55 @@ __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long lon
     }
 }
 
-// one WAVE per channel (four channels per 256-thread workgroup): fp64 sums of that channel's two partial rows, combined across the
-// lanes without LDS or barriers.  Valid in every lane on return.
+// Sums of one channel's two partial rows in fp64, fixed order (deterministic), no atomics.  Few partials (nblk <= kBnFinalizeWideFrom):
+// one WAVE per channel, four channels per 256-thread workgroup, combined across the lanes by shuffles.  Many (the million-row
+// tensors: up to 2048 per row): one 256-thread WORKGROUP per channel -- a wave alone walked 32 dependent-latency steps per lane
+// (8-9 us per finalize launch, 120 launches per step); four waves with all of a lane's <= 8 loads requested up front take a
+// third of that.  Valid in every lane of the channel's first wave on return (`owner`).
 constexpr int kBnFinalizeChannels = 4;
-__device__ __forceinline__ int bn_finalize_channel() { return blockIdx.x * kBnFinalizeChannels + (threadIdx.x >> 6); }
+constexpr int kBnFinalizeWideFrom = 256;
+__host__ __device__ inline bool bn_finalize_wide(int nblk) { return nblk > kBnFinalizeWideFrom; }
+static inline int bn_finalize_grid(int c, int nblk) { return bn_finalize_wide(nblk) ? c : (c + kBnFinalizeChannels - 1) / kBnFinalizeChannels; }
+__device__ __forceinline__ int bn_finalize_channel(int nblk)
+{
+    return bn_finalize_wide(nblk) ? static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x * kBnFinalizeChannels + (threadIdx.x >> 6));
+}
 
-__device__ __forceinline__ void bn_reduce_channel(const float *__restrict__ partial, int c, int nblk, int ch, double &s,
+// returns true in the lanes that hold the result (all lanes of the channel's first wave)
+__device__ __forceinline__ bool bn_reduce_channel(const float *__restrict__ partial, int c, int nblk, int ch, double &s,
                                                   double &q)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ double cross[2][kBnFinalizeChannels];
+    const bool wide = bn_finalize_wide(nblk);   // uniform over the grid
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = wide ? static_cast<int>(threadIdx.x) : lane, stride = wide ? 64 * kBnFinalizeChannels : 64;
     double a = 0.0, b = 0.0;
     const float *p0 = partial + static_cast<size_t>(ch) * kBnMaxBlocks;
     const float *p1 = partial + static_cast<size_t>(c + ch) * kBnMaxBlocks;
-    for (int i = lane; i < nblk; i += 64) { a += static_cast<double>(p0[i]); b += static_cast<double>(p1[i]); }
+    constexpr int kBatch = 8;
+    for (int i = first; i < nblk; i += stride * kBatch) {
+        float va[kBatch], vb[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int k = i + u * stride;
+            va[u] = k < nblk ? p0[k] : 0.0f;
+            vb[u] = k < nblk ? p1[k] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) { a += static_cast<double>(va[u]); b += static_cast<double>(vb[u]); }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if (wide) {
+        if (lane == 0) { cross[0][wave] = a; cross[1][wave] = b; }
+        __syncthreads();
+        a = cross[0][0]; b = cross[1][0];
+#pragma unroll
+        for (int w = 1; w < kBnFinalizeChannels; ++w) { a += cross[0][w]; b += cross[1][w]; }
+    }
     s = a;
     q = b;
+    return !wide || wave == 0;
 }
 
 // batch statistics, running statistics: running = (1-m)*running + m*batch with the BIASED batch variance -- what
@@ -219,11 +251,10 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, 
         z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
         seed_out[0] = z ^ (z >> 31);
     }
-    const int ch = bn_finalize_channel();
-    if (ch >= c) return;
+    const int ch = bn_finalize_channel(nblk);
+    if (ch >= c) return;   // whole waves (narrow form) or whole workgroups (wide form) leave together
     double s, q;
-    bn_reduce_channel(partial, c, nblk, ch, s, q);
-    if ((threadIdx.x & 63) != 0) return;
+    if (!bn_reduce_channel(partial, c, nblk, ch, s, q) || (threadIdx.x & 63) != 0) return;
     const double mean = s / static_cast<double>(rows);
     double var = q / static_cast<double>(rows) - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -349,11 +380,10 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int c, int nblk, const float *__restrict__ partial,
                                                               float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
-    const int ch = bn_finalize_channel();
+    const int ch = bn_finalize_channel(nblk);
     if (ch >= c) return;
     double s1, s2;
-    bn_reduce_channel(partial, c, nblk, ch, s1, s2);
-    if ((threadIdx.x & 63) != 0) return;
+    if (!bn_reduce_channel(partial, c, nblk, ch, s1, s2) || (threadIdx.x & 63) != 0) return;
     dbeta[ch] = static_cast<float>(s1);
     dgamma[ch] = static_cast<float>(s2);
 }
@@ -433,11 +463,10 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
 __global__ __launch_bounds__(256) void bn_colsum_finalize_kernel(int c, int nblk, const float *__restrict__ partial,
                                                                  float *__restrict__ colsum)
 {
-    const int ch = bn_finalize_channel();
+    const int ch = bn_finalize_channel(nblk);
     if (ch >= c) return;
     double s, q;
-    bn_reduce_channel(partial, c, nblk, ch, s, q);
-    if ((threadIdx.x & 63) == 0) colsum[ch] = static_cast<float>(s);
+    if (bn_reduce_channel(partial, c, nblk, ch, s, q) && (threadIdx.x & 63) == 0) colsum[ch] = static_cast<float>(s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -806,13 +835,13 @@ __global__ void bn_pool_bwd_dx_kernel(long long rows, int k, int c, int cv, int 
 void launch_bn_stats_finalize(long long rows, int c, int nblk, const float *partial, float eps, float momentum,
                               float *running_mean, float *running_var, float *save_mean, float *save_invstd, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, nblk, partial, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(bn_finalize_grid(c, nblk)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, nblk, partial, eps, momentum,
                        running_mean, running_var, save_mean, save_invstd, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), 0ull);
 }
 
 void launch_bn_bwd_finalize(int c, int nblk, const float *partial, float *dgamma, float *dbeta, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, nblk, partial, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_finalize_grid(c, nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, nblk, partial, dgamma, dbeta);
 }
 
 // dx (rows, cin) = g (rows, cout) W (cout, cin) for a HANDFUL of outputs (the segmentation head, rpn_model.py: 256 -> classes + 1).
@@ -962,7 +991,7 @@ HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const 
     }
     float *partial = static_cast<float *>(workspace);
     launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), 0ull);
     launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
     return launch_status();
@@ -1024,11 +1053,11 @@ HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float 
     }
     float *partial = static_cast<float *>(workspace);
     launch_bn_bwd_reduce(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
     float *cpart = dx_colsum ? partial : nullptr;  // the reduce partials were consumed by the finalize kernel above
     launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy);
     if (dx_colsum)
-        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, cpart, dx_colsum);
+        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, cpart, dx_colsum);
     return launch_status();
 }
 
@@ -1065,7 +1094,7 @@ HF_API int hf_bn_dropout_fwd_train(long long rows, int c, const float *x, const 
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, drop_state, seed_out, salt);
     launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, static_cast<long long>(c), d);
     return launch_status();
@@ -1085,7 +1114,7 @@ HF_API int hf_bn_dropout_bwd(long long rows, int c, const float *x, const float 
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
     launch_bn_bwd_reduce(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, static_cast<long long>(c), d);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
     launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, nullptr, static_cast<long long>(c), d);
     return launch_status();
 }
@@ -1133,7 +1162,7 @@ HF_API int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z
         if (g.vec == 4 && !aligned16(z)) return HF_EINVAL;
         float *partial = static_cast<float *>(workspace);
         launch_bn_stats(g, st, rows, c, z, partial, false);
-        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps, momentum,
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps, momentum,
                            running_mean, running_var, mean, invstd, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), 0ull);
     }
     BnGeom gg = bn_geom(groups, c);
@@ -1171,7 +1200,7 @@ HF_API int hf_bn_relu_maxpool_bwd(long long groups, int k, int c, const float *z
     else
         hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<1>), dim3(gg.nblk), dim3(gg.threads), lds_g, st, groups, k, c, gg.cv,
                            gg.rpb, gg.rows_per_block, z, dpooled, argmax, gamma, beta, save_mean, save_invstd, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, gg.nblk, partial, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_finalize_grid(c, gg.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, gg.nblk, partial, dgamma, dbeta);
     float *cpart = dz_colsum ? partial : nullptr;
     if (g.vec == 4)
         hipLaunchKernelGGL((bn_pool_bwd_dx_kernel<4>), dim3(g.nblk), dim3(g.threads), lds_r, st, rows, k, c, g.cv, g.rpb,
@@ -1181,6 +1210,6 @@ HF_API int hf_bn_relu_maxpool_bwd(long long groups, int k, int c, const float *z
         hipLaunchKernelGGL((bn_pool_bwd_dx_kernel<1>), dim3(g.nblk), dim3(g.threads), lds_r, st, rows, k, c, g.cv, g.rpb,
                            g.rows_per_block, z, dpooled, argmax, gamma, beta, save_mean, save_invstd, dgamma, dbeta, dz,
                            cpart);
-    if (dz_colsum) hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(div_up(c, kBnFinalizeChannels)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, cpart, dz_colsum);
+    if (dz_colsum) hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, cpart, dz_colsum);
     return launch_status();
 }
