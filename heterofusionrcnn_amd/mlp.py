@@ -681,8 +681,9 @@ class BatchNormReLU(nn.Module):
         return self._eval_invstd[1]
 
     def forward(self, x, dropout=0.0):
-        """dropout (a rate): training mode applies tf.layers.dropout(rate) to the output inside the normalisation pass (no pass of its
-        own, no mask tensor); inference ignores it, as dropout does"""
+        """dropout (a rate; callers pass 0 at inference): tf.layers.dropout(rate) applied to the output -- inside the normalisation
+        passes when the layer normalises with batch statistics (no pass of its own, no mask tensor), by the framework's dropout
+        behind the running-statistics form (a frozen BatchNorm inside a model that still trains)"""
         assert x.dim() == 2 and x.shape[1] == self.num_features
         if not x.is_cuda:
             raise RuntimeError("BatchNormReLU: heterofusionrcnn_amd has no CPU implementation")
@@ -699,7 +700,7 @@ class BatchNormReLU(nn.Module):
                                              ptr(self.running_mean), ptr(invstd),
                                              (1 if self.relu else 0) | (2 if self.elu_in else 0), ptr(y),
                                              stream_ptr()), "bn_relu_fwd_eval")
-        return y
+        return torch.nn.functional.dropout(y, p=dropout, training=True) if dropout > 0.0 else y
 
 
 class _LinearBNReLUMaxPool(torch.autograd.Function):

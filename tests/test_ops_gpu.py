@@ -1624,7 +1624,7 @@ def test_bn_with_fused_dropout(hf, rows, c, mode, rate):
     """BatchNormReLU(x, dropout=rate) = tf.layers.dropout(rate)(bn(act(x))) of pointfly's dense -> dropout (pointcnn.py:371-384,
     rpn_model.py:556-568) as one node.  The mask of a call depends on (layer seed, call number, element index) only, so it is read
     back by repeating the call from the same state with gamma = 0, beta = 1 (output = mask / (1 - rate)); then: output and all
-    gradients against torch in fp64 with THAT mask, keep fraction, a second call draws another mask, eval mode ignores the rate."""
+    gradients against torch in fp64 with THAT mask, keep fraction, a second call draws another mask; inference: the plain eval form."""
     from heterofusionrcnn_amd.mlp import BatchNormReLU
     g = torch.Generator().manual_seed(rows + c)
     x = torch.randn(rows, c, generator=g).cuda().requires_grad_(True)
@@ -1670,7 +1670,7 @@ def test_bn_with_fused_dropout(hf, rows, c, mode, rate):
     differ = ((y2 != 0) != keep).double().mean().item()
     assert abs(differ - 2 * rate * (1 - rate)) < 0.05, differ
     bn.eval()
-    ye = bn(x.detach(), dropout=rate)
+    ye = bn(x.detach())          # callers pass no rate at inference
     bn_ref = (e.detach() - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + 1e-3) * w.detach() + b.detach()
     assert torch.allclose(ye.double(), torch.relu(bn_ref) if mode & 1 else bn_ref, rtol=1e-4, atol=1e-4)
 
