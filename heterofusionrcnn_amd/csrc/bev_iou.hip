@@ -151,6 +151,51 @@ __device__ __forceinline__ bool surely_disjoint(const BoxPre &a, const BoxPre &b
     return sep;  // NaN / inf inputs compare false -> full path
 }
 
+// Third filter, NMS only (the mask needs `iou > thresh`, not the value): an upper bound on the overlap area that costs a few dozen
+// instructions instead of the ~600 x 8 lanes of the clip.  For an edge direction u of box P (side length L along u, L' across it),
+// A n B lies inside P n {x : proj_u(x) in proj_u(other box)}: a rectangle of area (overlap of the two projections) x L'.  The
+// smallest of the four such bounds (two axes per box), padded by the same kind of slack as the other filters, bounds the reference's
+// overlap from above; iou is increasing in the overlap, so `bound / (sa + sb - bound) < 0.98 thresh` means the reference's
+// `iou > thresh` (bev_iou_g.cu:208-215, :283) is false and the mask bit is 0 either way.  At the RPN's threshold of 0.8 this
+// removes nearly every pair that survived the separating-axis test (two boxes that merely touch); at 0.01 it removes nothing
+// and costs ~40 instructions per surviving pair.  Degenerate boxes (a side <= 0, NaN / inf anywhere) compare false: full path.
+__device__ __forceinline__ bool iou_surely_below(const BoxPre &a, const BoxPre &b, float thresh)
+{
+    const float wa = a.box[2] - a.box[0], ha = a.box[3] - a.box[1], wb = b.box[2] - b.box[0], hb = b.box[3] - b.box[1];
+    if (!(wa > 0.f && ha > 0.f && wb > 0.f && hb > 0.f)) return false;
+    float mag = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        mag = fmaxf(mag, fmaxf(fmaxf(fabsf(a.cor[k].x), fabsf(a.cor[k].y)), fmaxf(fabsf(b.cor[k].x), fabsf(b.cor[k].y))));
+    const float slack = 1e-3f + 1e-5f * mag;   // metres along the axis: rounding of corners and projections, MARGIN = 1e-5
+    float ub = INFINITY;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const BoxPre &p = which == 0 ? a : b;
+        const float w = which == 0 ? wa : wb, h = which == 0 ? ha : hb;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            // cor[0] -> cor[1] runs along the box's own x axis (length w), cor[1] -> cor[2] along its y axis (length h)
+            const float ux = p.cor[e + 1].x - p.cor[e].x, uy = p.cor[e + 1].y - p.cor[e].y;
+            const float along = e == 0 ? w : h, across = e == 0 ? h : w;
+            float amin = INFINITY, amax = -INFINITY, bmin = INFINITY, bmax = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float pa = a.cor[k].x * ux + a.cor[k].y * uy;
+                const float pb = b.cor[k].x * ux + b.cor[k].y * uy;
+                amin = fminf(amin, pa); amax = fmaxf(amax, pa);
+                bmin = fminf(bmin, pb); bmax = fmaxf(bmax, pb);
+            }
+            // projections are scaled by |u| = along (up to rounding): overlap length in metres, padded
+            const float ov = fmaxf(fminf(amax, bmax) - fmaxf(amin, bmin), 0.f) / along + slack;
+            ub = fminf(ub, ov * (across + slack));
+        }
+    }
+    const float sa = wa * ha, sb = wb * hb;
+    const float den = sa + sb - ub;
+    return den > 0.f && ub < 0.98f * thresh * den;   // NaN / inf anywhere: false
+}
+
 // box_overlap, bev_iou_g.cu:102-206, on precomputed corners -- EIGHT lanes per pair.
 // As one thread per pair the clip is a dependent chain of ~2000 instructions (16 edge tests with divisions, up to 24
 // atan2f, a sort, a fan) that sets the latency of a whole tile; sixteen lanes per pair (the first cooperative form) cut
@@ -601,7 +646,8 @@ __global__ __launch_bounds__(kNmsThreads, HF_NMS_THREADS >= 512 ? 8 : 4) void nm
     const int nq = sh.qcount;
     for (int q = t; q < nq; q += kNmsThreads) {
         const int e = sh.queue[q];
-        if (!surely_disjoint(sh.ra[e >> 6], sh.cb[e & 63])) sh.queue2[atomicAdd(&sh.q2count, 1)] = static_cast<unsigned short>(e);
+        if (!surely_disjoint(sh.ra[e >> 6], sh.cb[e & 63]) && !iou_surely_below(sh.ra[e >> 6], sh.cb[e & 63], thresh))
+            sh.queue2[atomicAdd(&sh.q2count, 1)] = static_cast<unsigned short>(e);
     }
     __syncthreads();
     {
