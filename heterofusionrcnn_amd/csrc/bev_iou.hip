@@ -80,7 +80,7 @@ __device__ __forceinline__ Pt rot_center(Pt c, float ac, float as, Pt p)
 // Everything about one box that does not depend on its partner: evaluated once per box per tile
 // (the reference recomputes cos/sin and the rotated corners for every pair, bev_iou_g.cu:130-140).
 struct __attribute__((aligned(16))) BoxPre {
-    float cx, cy, rad, mag; // centre, a bound on the circumradius (half perimeter), |cx| + |cy| + rad: the first filter
+    float cx, cy, rad, mag; // centre, the circumradius (half diagonal), |cx| + |cy| + rad: the first filter
                             // reads these four with one 16-byte LDS access
     Pt cor[4];              // rotated corners, order of bev_iou_g.cu:118-128
     float cs, sn;           // cos(angle), sin(angle)
@@ -103,7 +103,11 @@ __device__ __forceinline__ void box_precompute(const float *b, BoxPre &o)
     o.cor[3] = rot_center(c, o.cs, o.sn, Pt{ b[0], b[3] });
     o.cx = c.x;
     o.cy = c.y;
-    o.rad = (fabsf(b[2] - b[0]) + fabsf(b[3] - b[1])) * 0.5f;
+    // half the diagonal: the distance from the centre to every rotated corner (rotation keeps it; its fp32 rounding is covered
+    // by the filters' slack of 1e-3 + 1e-5 * mag).  Round 4: was the half perimeter (w + h) / 2, which is 30 % longer for a
+    // 3.9 x 1.6 box -- 1.7 x as many pairs survived the circle filter and went through the separating-axis test
+    const float bw = b[2] - b[0], bh = b[3] - b[1];
+    o.rad = 0.5f * sqrtf(bw * bw + bh * bh) * 1.000001f;
     o.mag = fabsf(o.cx) + fabsf(o.cy) + o.rad;
 }
 
@@ -153,8 +157,9 @@ __device__ __forceinline__ bool surely_disjoint(const BoxPre &a, const BoxPre &b
 
 // Third filter, NMS only (the mask needs `iou > thresh`, not the value): an upper bound on the overlap area that costs a few dozen
 // instructions instead of the ~600 x 8 lanes of the clip.  For an edge direction u of box P (side length L along u, L' across it),
-// A n B lies inside P n {x : proj_u(x) in proj_u(other box)}: a rectangle of area (overlap of the two projections) x L'.  The
-// smallest of the four such bounds (two axes per box), padded by the same kind of slack as the other filters, bounds the reference's
+// A n B lies inside P n {x : proj_u(x) in proj_u(other box)}: a rectangle of area (overlap of the two projections) x L' -- and
+// inside the intersection of P's two such slabs, the rectangle (overlap along u) x (overlap along u').  The
+// smallest of these six bounds (per box: two slabs and their product), padded by the same kind of slack as the other filters, bounds the reference's
 // overlap from above; iou is increasing in the overlap, so `bound / (sa + sb - bound) < 0.98 thresh` means the reference's
 // `iou > thresh` (bev_iou_g.cu:208-215, :283) is false and the mask bit is 0 either way.  At the RPN's threshold of 0.8 this
 // removes nearly every pair that survived the separating-axis test (two boxes that merely touch); at 0.01 it removes nothing
@@ -173,6 +178,7 @@ __device__ __forceinline__ bool iou_surely_below(const BoxPre &a, const BoxPre &
     for (int which = 0; which < 2; ++which) {
         const BoxPre &p = which == 0 ? a : b;
         const float w = which == 0 ? wa : wb, h = which == 0 ? ha : hb;
+        float both = 1.0f;   // in P's own frame A n B also lies inside the rectangle [overlap along x] x [overlap along y]
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             // cor[0] -> cor[1] runs along the box's own x axis (length w), cor[1] -> cor[2] along its y axis (length h)
@@ -189,7 +195,9 @@ __device__ __forceinline__ bool iou_surely_below(const BoxPre &a, const BoxPre &
             // projections are scaled by |u| = along (up to rounding): overlap length in metres, padded
             const float ov = fmaxf(fminf(amax, bmax) - fmaxf(amin, bmin), 0.f) / along + slack;
             ub = fminf(ub, ov * (across + slack));
+            both *= ov;
         }
+        ub = fminf(ub, both);
     }
     const float sa = wa * ha, sb = wb * hb;
     const float den = sa + sb - ub;
@@ -616,33 +624,55 @@ __global__ __launch_bounds__(kNmsThreads, HF_NMS_THREADS >= 512 ? 8 : 4) void nm
         tile_stage(sh, boxes, row_t * 64, row_size, boxes, col_t * 64, col_size);
     }
     __syncthreads();
-    // filter 1: bounding circles, four fixed columns per thread in registers (as in bev_iou_kernel), rows 16 apart
+#if defined(HF_NMS_PHASE_STOP)
+    if (HF_NMS_PHASE_STOP == 1) return;   // diagnostic variant builds only (scripts/probes/build_bev_variant.sh): phase costs
+#endif
+    // filter 1: bounding circles, four fixed columns per thread in registers, rows kNmsThreads / 16 apart; pairs go two at a time
+    // through the packed fp32 instructions (as in bev_iou_kernel), and a thread's survivors are pushed in one go at the end -- the
+    // per-pair form ran eight exec-masked branch regions with an LDS atomic each per thread (~130 instructions; this: ~80)
     {
         const int c0 = (t & 15) * 4;
-        float bx[4], by[4], bs[4];
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v bx[2], by[2], bs[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float4 q = *reinterpret_cast<const float4 *>(&sh.cb[min(c0 + i, 63)]);
-            bx[i] = q.x; by[i] = q.y; bs[i] = q.z + 1e-3f + 1e-5f * q.w;
+            bx[i >> 1][i & 1] = q.x; by[i >> 1][i & 1] = q.y; bs[i >> 1][i & 1] = q.z + 1e-3f + 1e-5f * q.w;
         }
-        if (c0 < col_size) {
-            for (int r = t >> 4; r < row_size; r += kNmsThreads / 16) {
-                const float4 a = *reinterpret_cast<const float4 *>(&sh.ra[r]);   // cx, cy, rad, mag
-                const float as = a.z + 1e-5f * a.w;
+        constexpr int kRowStep = kNmsThreads / 16;
+        static_assert(64 / kRowStep <= 8, "four bits per row step in one register");
+        unsigned surv = 0u;   // my pairs that go on: bit 4 * step + column
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = c0 + i;
-                    const float reach = bs[i] + as;
-                    const float dx = bx[i] - a.x, dy = by[i] - a.y;
-                    const bool valid = c < col_size && !(row_t == col_t && c <= r);
-                    // NaN / inf compare false -> next filter
-                    if (valid && !(dx * dx + dy * dy > reach * reach))
-                        sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | c);
+        for (int it = 0; it < 64 / kRowStep; ++it) {
+            const int r = (t >> 4) + it * kRowStep;
+            const bool live = r < row_size && c0 < col_size;
+            const float4 a = *reinterpret_cast<const float4 *>(&sh.ra[live ? r : 0]);   // cx, cy, rad, mag
+            const float as = a.z + 1e-5f * a.w;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // = circles_apart(): NaN / inf compare false -> next filter
+                const f2v reach = bs[h] + as;
+                const f2v dx = bx[h] - a.x, dy = by[h] - a.y;
+                const f2v d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+                const f2v r2 = reach * reach;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = c0 + 2 * h + u;
+                    const bool valid = live && c < col_size && !(row_t == col_t && c <= r);
+                    if (valid && !(d2[u] > r2[u])) surv |= 1u << (4 * it + 2 * h + u);
                 }
             }
         }
+        for (; surv; surv &= surv - 1u) {
+            const int b = __builtin_ctz(surv);
+            const int r = (t >> 4) + (b >> 2) * kRowStep;
+            sh.queue[atomicAdd(&sh.qcount, 1)] = static_cast<unsigned short>((r << 6) | (c0 + (b & 3)));
+        }
     }
     __syncthreads();
+#if defined(HF_NMS_PHASE_STOP)
+    if (HF_NMS_PHASE_STOP == 2) return;
+#endif
     const int nq = sh.qcount;
     for (int q = t; q < nq; q += kNmsThreads) {
         const int e = sh.queue[q];
@@ -650,8 +680,15 @@ __global__ __launch_bounds__(kNmsThreads, HF_NMS_THREADS >= 512 ? 8 : 4) void nm
             sh.queue2[atomicAdd(&sh.q2count, 1)] = static_cast<unsigned short>(e);
     }
     __syncthreads();
+#if defined(HF_NMS_PHASE_STOP)
+    if (HF_NMS_PHASE_STOP == 3) return;
+#endif
     {
+#if defined(HF_NMS_PHASE_STOP)
+        const int nq2 = HF_NMS_PHASE_STOP == 4 ? 0 : sh.q2count;   // 4: no clip at all
+#else
         const int nq2 = sh.q2count;
+#endif
         const int grp = t / kClipLanes, sub = t % kClipLanes;
         for (int q0 = 0; q0 < nq2; q0 += kNmsThreads / kClipLanes) {
             const int q = q0 + grp;
@@ -663,10 +700,15 @@ __global__ __launch_bounds__(kNmsThreads, HF_NMS_THREADS >= 512 ? 8 : 4) void nm
         }
     }
     __syncthreads();
+#if defined(HF_NMS_PHASE_STOP)
+    if (HF_NMS_PHASE_STOP == 5) return;   // everything but the stores
+#endif
     const int col_blocks = (n + 63) / 64;
     if (t < row_size) {
         const unsigned long long w = sh.words[t];
-        mask[(static_cast<size_t>(row_t) * 64 + t) * col_blocks + col_t] = w;
+        // hf_oriented_nms clears the dense mask with one memset and its tiles store their NONZERO words only (64 eight-byte stores
+        // to 64 different lines per tile: 640 000 partial-line writes at 9000 boxes, nearly all of them zeros)
+        if (!UPPER_ONLY || w != 0ull) mask[(static_cast<size_t>(row_t) * 64 + t) * col_blocks + col_t] = w;
         if (UPPER_ONLY && col_t == row_t + 1)   // the word next to the diagonal: the sweep's resolving wave adds these itself
             reinterpret_cast<unsigned long long *>(ws + nms_ws_nextw_offset(n))[row_t * 64 + t] = w;
         if (UPPER_ONLY && col_t > row_t + 1 && w != 0ull) {
@@ -1108,8 +1150,9 @@ HF_API int hf_oriented_nms_batched(int frames, const float *boxes, int n, float 
     hipStream_t st = as_stream(stream);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     const size_t ws_stride = nms_ws_bytes(n);
-    // the list counters start at zero (one strided memset: they sit at the same offset of every frame's workspace)
-    int rc = hip_status(hipMemset2DAsync(ws + nms_ws_counts_offset(n), ws_stride, 0, sizeof(int) * static_cast<size_t>(cb), frames, st));
+    // the dense mask (its tiles store nonzero words only) and the list counters behind it start at zero: one strided memset over
+    // [mask | counters] of every frame's workspace (the counters follow the mask, padded to 256 bytes)
+    int rc = hip_status(hipMemset2DAsync(ws, ws_stride, 0, nms_ws_counts_offset(n) + sizeof(int) * static_cast<size_t>(cb), frames, st));
     if (rc != HF_OK) return rc;
     hipLaunchKernelGGL(nms_boxpre_kernel, dim3(div_up(n, 256), frames), dim3(256), 0, st, n, boxes, ws, ws_stride);
     if (const int lrc = tile_lds_attr(&nms_mask_kernel<true>); lrc != HF_OK) return lrc;

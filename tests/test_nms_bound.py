@@ -32,12 +32,15 @@ def _rejected(a, b, ca, cb, thresh):
     slack = f32(1e-3) + f32(1e-5) * max(np.abs(ca).max(), np.abs(cb).max())
     ub = np.inf
     for p, w, h in ((ca, wa, ha), (cb, wb, hb)):
+        both = f32(1.0)
         for e in range(2):
             u = p[e + 1] - p[e]
             along, across = (w, h) if e == 0 else (h, w)
             pa, pb = ca @ u, cb @ u
             ov = max(min(pa.max(), pb.max()) - max(pa.min(), pb.min()), 0) / along + slack
             ub = min(ub, ov * (across + slack))
+            both = both * ov
+        ub = min(ub, both)
     den = wa * ha + wb * hb - ub
     return bool(den > 0 and ub < f32(0.98) * f32(thresh) * den)
 
