@@ -586,12 +586,15 @@ class XConv(nn.Module):
             _, idx = knn_point(self.k * self.d, pts, qrs)
             return idx[:, :, ::self.d].contiguous() if self.d > 1 else idx
 
-    def forward(self, pts, fts, qrs, idx=None, inverse=None, skip=None, ahead=False):
+    def forward(self, pts, fts, qrs, idx=None, inverse=None, skip=None, ahead=False, local=None):
         """inverse = index_inverse(idx, N) prepared with the geometry: the gradient of the feature gather then gathers too.
         skip (B,P,Cs): returns [x-conv output | skip] (the concat of an X-DeConv with the encoder features, pointcnn.py:349).
-        ahead: the caller forked the side streams after pts / qrs / idx were in place (fork_side_streams)"""
+        ahead: the caller forked the side streams after pts / qrs / idx were in place (fork_side_streams).
+        local (B,P,K,3) = the neighbours' offsets P' = P - p (pointcnn.py:96), coordinates only: prepared with the geometry
+        (PointCnnBackbone.geometry), else gathered here -- by each of the two branches that read it"""
         idx = idx if idx is not None else self.neighbours(pts, qrs)
         b, p, k = idx.shape
+        offsets = (lambda: local) if local is not None else (lambda: group_point(pts, idx) - qrs.unsqueeze(2))
         bn1 = self.lift1.post.bn
         c_delta = self.lift1.linear.out_features
         x = side = lside = None
@@ -603,7 +606,7 @@ class XConv(nn.Module):
             if not ahead:
                 side.wait_stream(cur)
             with torch.cuda.stream(side):
-                x = self._x_transform(group_point(pts, idx) - qrs.unsqueeze(2), b, p, k)
+                x = self._x_transform(offsets(), b, p, k)
             if b * p * k <= CONCURRENT_LIFT_BRANCH_MAX_ROWS:
                 lside = _side_stream(pts.device, 1)
                 if not ahead:
@@ -612,7 +615,7 @@ class XConv(nn.Module):
         fuse_concat = (not gather) and fts is not None and _fusable(bn1, fts, c_delta, c_delta + fts.shape[-1])
         # the coordinate-only part of the lifting branch (on its side stream when there is one) ...
         with torch.cuda.stream(lside) if lside is not None else contextlib.nullcontext():
-            local = group_point(pts, idx) - qrs.unsqueeze(2)     # (B,P,K,3)  P' <- P - p
+            local = offsets()                                    # (B,P,K,3)  P' <- P - p
             if gather:
                 f = dense_chain(self.lift0, self.lift1, local)    # F_delta alone: the neighbours' features are read in place below
             elif fuse_concat:
@@ -720,7 +723,12 @@ class PointCnnBackbone(nn.Module):
             inv = lambda idx, n: index_inverse(idx, n) if (self.training and n <= INVERSE_MAX_TARGETS) else None   # a backward pass only
             enc_inv = [inv(ix, pts[li].shape[1]) for li, ix in enumerate(enc_idx)]
             dec_inv = [inv(ix, pts[pi + 1].shape[1]) for ix, (k, d, pi, qi) in zip(dec_idx, self.cfg.xdconv)]
-        return {"pts": pts, "enc": enc_idx, "dec": dec_idx, "enc_inv": enc_inv, "dec_inv": dec_inv}
+            # the neighbours' offsets P' = P - p of every layer (pointcnn.py:96): read by the lifting branch AND by the
+            # X-transformation branch of the layer -- two gathers and two subtractions per layer inside the step otherwise
+            enc_local = [group_point(pts[li], ix) - pts[li + 1].unsqueeze(2) for li, ix in enumerate(enc_idx)]
+            dec_local = [group_point(pts[pi + 1], ix) - pts[qi + 1].unsqueeze(2) for ix, (k, d, pi, qi) in zip(dec_idx, self.cfg.xdconv)]
+        return {"pts": pts, "enc": enc_idx, "dec": dec_idx, "enc_inv": enc_inv, "dec_inv": dec_inv, "enc_local": enc_local,
+                "dec_local": dec_local}
 
     def forward(self, xyz, features, geometry=None, taps=None):
         """taps (a list): filled with (output, detached copy) of every encoder layer -- each tensor that flows from the encoder
@@ -732,7 +740,8 @@ class PointCnnBackbone(nn.Module):
         if ahead:
             fork_side_streams(xyz.device)      # the geometry is in place: the coordinate-only branches of every layer may start
         for li, m in enumerate(self.enc):
-            fts.append(m(pts[li], fts[-1], pts[li + 1], g["enc"][li], g.get("enc_inv", [None] * len(self.enc))[li], ahead=ahead))
+            fts.append(m(pts[li], fts[-1], pts[li + 1], g["enc"][li], g.get("enc_inv", [None] * len(self.enc))[li], ahead=ahead,
+                         local=g.get("enc_local", [None] * len(self.enc))[li]))
         if taps is not None:
             # a clean cut: the decoder (and everything after it) reads detached copies that are leaves of their own graph, so
             # d loss / d copy holds the downstream paths only; the encoder's own chain (layer i+1 reads layer i) stays on the
@@ -744,7 +753,7 @@ class PointCnnBackbone(nn.Module):
         for li, (k, d, pi, qi) in enumerate(self.cfg.xdconv):
             src = fts[pi + 1] if li == 0 else cur
             x = self.dec[li](pts[pi + 1], src, pts[qi + 1], g["dec"][li], g.get("dec_inv", [None] * len(self.dec))[li], skip=fts[qi + 1],
-                             ahead=ahead)
+                             ahead=ahead, local=g.get("dec_local", [None] * len(self.dec))[li])
             cur = self.fuse[li](x)                                   # x = [x-deconv | encoder features of the query layer]
         out = cur if cur is not None else fts[-1]        # no decoder (the RCNN's extractor): the last encoder layer
         for layer, rate in zip(self.fc, self.fc_drop):
