@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kAdamThreads) void adam_multi_kernel(const AdamEntr
 }
 
 // ---- several device-to-device copies in one launch (the refresh of a captured step's input slots) ----
-constexpr int kCopyMax = 64;            // 3 x 8 x 64 = 1.5 KB of kernel arguments
+constexpr int kCopyMax = 64;            // 3 x 8 x 64 + 4 x 65 = 1.8 KB of kernel arguments
 constexpr int kCopyChunk = 64 * 1024;   // bytes per workgroup
 constexpr int kCopyThreads = 256;
 
@@ -83,13 +83,24 @@ struct CopyList {
     void *dst[kCopyMax];
     const void *src[kCopyMax];
     long long bytes[kCopyMax];
+    int first[kCopyMax + 1];            // first workgroup of every copy (prefix sums of their chunk counts); first[n .. kCopyMax] = all
 };
 
+// One workgroup per 64 KB chunk of SOME copy: a flat grid over all chunks, the copy found by a binary search of the prefix table
+// (scalar loads of kernel arguments).  The first form launched (chunks of the longest copy) x (copies) workgroups -- 844 x 50 for a
+// step whose inputs hold one 55 MB feature map and fifty small tables: 42 000 workgroups, all but ~1000 of them leaving at once,
+// 97 us for 60 MB.
 __global__ __launch_bounds__(kCopyThreads) void copy_multi_kernel(CopyList list)
 {
-    const int which = blockIdx.y;
+    int lo = 0, hi = kCopyMax - 1;      // largest `which` with first[which] <= blockIdx.x (first[0] = 0)
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {   // 2^6 = kCopyMax
+        const int mid = (lo + hi + 1) >> 1;
+        if (list.first[mid] <= static_cast<int>(blockIdx.x)) lo = mid; else hi = mid - 1;
+    }
+    const int which = lo;
     const long long total = list.bytes[which];
-    const long long o0 = static_cast<long long>(blockIdx.x) * kCopyChunk;
+    const long long o0 = static_cast<long long>(static_cast<int>(blockIdx.x) - list.first[which]) * kCopyChunk;
     if (o0 >= total) return;
     const long long n = total - o0 < kCopyChunk ? total - o0 : kCopyChunk;
     typedef __attribute__((address_space(1))) unsigned char gbyte;
@@ -117,19 +128,22 @@ HF_API int hf_copy_multi(int n, void *const *dst, const void *const *src, const 
     if (n < 0 || n > kCopyMax) return HF_EINVAL;
     if (n == 0) return HF_OK;
     if (!dst || !src || !bytes) return HF_EINVAL;
+    static_assert(kCopyMax == 64, "the kernel's binary search takes six steps");
     CopyList list;
-    long long longest = 0;
+    long long chunks = 0;
     for (int i = 0; i < n; ++i) {
         if (bytes[i] < 0 || (bytes[i] > 0 && (!dst[i] || !src[i]))) return HF_EINVAL;
         list.dst[i] = dst[i];
         list.src[i] = src[i];
         list.bytes[i] = bytes[i];
-        if (bytes[i] > longest) longest = bytes[i];
+        list.first[i] = static_cast<int>(chunks);
+        chunks += (bytes[i] + kCopyChunk - 1) / kCopyChunk;
+        if (chunks > 0x7fffffffLL) return HF_EINVAL;
     }
-    if (longest == 0) return HF_OK;
-    const long long chunks = (longest + kCopyChunk - 1) / kCopyChunk;
-    if (chunks > 0x7fffffffLL) return HF_EINVAL;
-    hipLaunchKernelGGL(copy_multi_kernel, dim3(static_cast<unsigned>(chunks), n), dim3(kCopyThreads), 0, as_stream(stream), list);
+    for (int i = n; i <= kCopyMax; ++i) list.first[i] = static_cast<int>(chunks);
+    for (int i = n; i < kCopyMax; ++i) { list.dst[i] = nullptr; list.src[i] = nullptr; list.bytes[i] = 0; }
+    if (chunks == 0) return HF_OK;
+    hipLaunchKernelGGL(copy_multi_kernel, dim3(static_cast<unsigned>(chunks)), dim3(kCopyThreads), 0, as_stream(stream), list);
     return launch_status();
 }
 
