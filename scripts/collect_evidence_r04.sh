@@ -30,4 +30,7 @@ python3 scripts/make_alu_json.py $OUT/bev_pmc $OUT/bev_tr $OUT/bev_iou_alu.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_f1 -o f1 -- python3 bench.py --frames-per-gpu 1 --steps 16 --warmup 3 --no-cpu-baseline --no-op-table --no-side-runs > $OUT/prof_f1.log 2>&1; echo "rocprof f1 exit $?"
 python scripts/probes/step_breakdown.py $(find $OUT/prof_bench -name "*kernel_trace.csv" | head -1) > $OUT/step_breakdown.txt 2>&1; head -3 $OUT/step_breakdown.txt
 rm -rf $OUT/bev_pmc/*/*agent_info.csv
+# the per-rank shapes of a global batch of 8 on 2 / 4 GPUs (strong scaling, BASELINE config 4), replayed
+for F in 4 2; do python bench.py --no-op-table --no-cpu-baseline --no-side-runs --frames-per-gpu $F --steps 32 2>/dev/null | python scripts/probes/show_bench.py - --short; done > $OUT/frames_per_gpu_4_2.txt; cat $OUT/frames_per_gpu_4_2.txt
+timeout -k 10 200 python scripts/probes/bn_stream_timing.py 2>/dev/null > $OUT/bn_stream_timing.txt
 echo done

@@ -16,4 +16,6 @@ cp $E/bev_nms_timing.json $P/r04_bev_nms_timing.json
 [ -f $E/bev_iou_alu.json ] && cp $E/bev_iou_alu.json $P/bev_iou_alu.json
 [ -f $E/prof_f1/f1_kernel_stats.csv ] && cp $E/prof_f1/f1_kernel_stats.csv $P/r04_bench_1frame_kernel_stats.csv
 [ -f $E/step_breakdown.txt ] && cp $E/step_breakdown.txt $P/r04_step_breakdown.txt
+[ -f $E/frames_per_gpu_4_2.txt ] && cp $E/frames_per_gpu_4_2.txt $P/r04_frames_per_gpu_4_2.txt
+[ -f $E/bn_stream_timing.txt ] && cp $E/bn_stream_timing.txt $P/r04_bn_stream_timing.txt
 echo published
