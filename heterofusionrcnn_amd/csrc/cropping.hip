@@ -13,11 +13,25 @@
 //            s (s < cnt) or (s - cnt) mod cnt (the reference's cyclic padding, :108-126);
 //            empty boxes get zeros / non_empty = false.  Every output element is written exactly
 //            once, so no memset passes are needed.
+// Round 4: both phases keep several independent loads of a thread in flight.  The first form scanned 64 points per trip (three
+// loads, wait, ballot: 64 dependent round trips per wave) and copied one 16-byte piece per thread and trip behind an integer
+// division by the channel count -- 131 us for 512 boxes x 512 points x 288 channels = 2.3 TB/s of output with two 256-thread
+// workgroups per CU.  Now: 1024 threads per box, four 64-point chunks (twelve loads) per trip of the scan, four pieces per trip of the
+// copy with (slot, piece) advanced incrementally.
 #include "hf_common.h"
 
 namespace hf {
 
-constexpr int kCropThreads = 256;
+#ifndef HF_CROP_THREADS
+#define HF_CROP_THREADS 1024   // 256 / 512 / 1024 threads per box: 107 / 88-93 / 82 us at 512 x 512 x 288 (scripts/probes/crop_timing.py, one run)
+#endif
+#ifndef HF_CROP_SCAN
+#define HF_CROP_SCAN 4
+#endif
+#ifndef HF_CROP_COPY
+#define HF_CROP_COPY 4
+#endif
+constexpr int kCropThreads = HF_CROP_THREADS;
 constexpr int kCropWaves = kCropThreads / kWave;
 
 // tf_cropping_g.cu:3-5
@@ -83,14 +97,23 @@ __global__ __launch_bounds__(kCropThreads) void crop_kernel(
         const int lo = wave * per, hi = min(npts, lo + per);
         int cnt = 0;  // wave-uniform
         int *mine = lists + wave * resize;
-        for (int p0 = lo; p0 < hi && cnt < resize; p0 += 64) {
-            const int p = p0 + lane;
-            bool in = false;
-            if (p < hi) in = inside(cbx, P[p * 3], P[p * 3 + 1], P[p * 3 + 2]);
-            const unsigned long long m = __ballot(in);
-            const int pos = cnt + mask_prefix(m);
-            if (in && pos < resize) mine[pos] = p;
-            cnt += __builtin_popcountll(m);
+        constexpr int kScan = HF_CROP_SCAN;   // 64-point chunks per trip: their loads go out together
+        for (int p0 = lo; p0 < hi && cnt < resize; p0 += 64 * kScan) {
+            float x[kScan], y[kScan], z[kScan];
+#pragma unroll
+            for (int u = 0; u < kScan; ++u) {
+                const int p = min(p0 + 64 * u + lane, hi - 1);   // past the end: a valid address, masked below
+                x[u] = P[p * 3]; y[u] = P[p * 3 + 1]; z[u] = P[p * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < kScan; ++u) {
+                const int p = p0 + 64 * u + lane;
+                const bool in = p < hi && inside(cbx, x[u], y[u], z[u]);
+                const unsigned long long m = __ballot(in);
+                const int pos = cnt + mask_prefix(m);
+                if (in && pos < resize) mine[pos] = p;
+                cnt += __builtin_popcountll(m);
+            }
         }
         if (lane == 0) wave_cnt[wave] = min(cnt, resize);
         __syncthreads();
@@ -140,10 +163,28 @@ __global__ __launch_bounds__(kCropThreads) void crop_kernel(
             const int cv = channel >> 2;
             const float4 *F4 = reinterpret_cast<const float4 *>(F);
             float4 *O4 = reinterpret_cast<float4 *>(crop_fts + ob * channel);
-            for (int i = t; i < resize * cv; i += kCropThreads) {
-                const int s = i / cv, d = i - s * cv;
-                const int e = src[s];
+            // piece i = (slot i / cv, 16-byte piece i % cv); a thread's pieces are kCropThreads apart: (slot, piece) advance by
+            // (kCropThreads / cv, kCropThreads % cv) with one carry -- no division inside the loop
+            const int total4 = resize * cv, ds = kCropThreads / cv, dd = kCropThreads % cv;
+            constexpr int kCopy = HF_CROP_COPY;
+            int i = t, sl = t / cv, d = t - sl * cv;
+            for (; i + (kCopy - 1) * kCropThreads < total4; i += kCopy * kCropThreads) {
+                float4 v[kCopy];
+#pragma unroll
+                for (int u = 0; u < kCopy; ++u) {
+                    const int e = src[sl];
+                    v[u] = e < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : F4[static_cast<size_t>(e) * cv + d];
+                    sl += ds; d += dd;
+                    if (d >= cv) { d -= cv; ++sl; }
+                }
+#pragma unroll
+                for (int u = 0; u < kCopy; ++u) O4[i + u * kCropThreads] = v[u];
+            }
+            for (; i < total4; i += kCropThreads) {
+                const int e = src[sl];
                 O4[i] = e < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : F4[static_cast<size_t>(e) * cv + d];
+                sl += ds; d += dd;
+                if (d >= cv) { d -= cv; ++sl; }
             }
         } else {
             for (int i = t; i < resize * channel; i += kCropThreads) {
