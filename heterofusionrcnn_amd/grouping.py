@@ -219,11 +219,12 @@ def select_top_k(k, dist):
     return outi, out
 
 
-def knn_point(k, xyz1, xyz2, all_pairs=False, dense=False):
+def knn_point(k, xyz1, xyz2, all_pairs=None, dense=False):
     """xyz1 (B,N,C) data, xyz2 (B,M,C) queries -> (val (B,M,k) squared L2 ascending, idx (B,M,k) int32).
     Reference: tf_grouping.py:62-95 (dense |q|^2 - 2 q.p^T + |p|^2 matrix + tf.nn.top_k).  For C == 3 this is
     the HIP kNN kernel (no (B,M,N) matrix; ties: lower index first): data binned into a 2-D grid + ring search for
-    N <= 65536, the tiled all-pairs kernel beyond that or with all_pairs=True.  Other channel counts or k > 67 RAISE
+    N <= 65536 (all_pairs=False forces it), the tiled all-pairs kernel beyond that, for tiny problems (N M <= 65536 per cloud) or
+    with all_pairs=True.  Other channel counts or k > 67 RAISE
     unless dense=True is passed, which takes the reference's three-term formula in framework ops (torch.topk tie order).
     PARITY UNPINNED against the reference where it matters for ties: the reference ranks the fp32 three-term expansion
     with tf.nn.top_k, this kernel ranks (q - p)^2 summed per axis with ties to the lower index.  The neighbour sets agree
@@ -243,6 +244,10 @@ def knn_point(k, xyz1, xyz2, all_pairs=False, dense=False):
         idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
         L = _lib.lib()
         nbytes = L.hf_knn_workspace(b, n)
+        # tiny problems (the RCNN's RoI clouds below its first layer: 512 x 128, 128 x 32, 32 x 8 per RoI, 800 RoIs) are faster on
+        # the all-pairs kernel than through binning + ring search (284 / 183 / 58 us against 421 / 332 / 149;
+        # scripts/probes/knn_small_timing.py); both kernels rank (q - p)^2 with ties to the lower index: same result
+        all_pairs = (n * m <= 65536) if all_pairs is None else bool(all_pairs)
         if nbytes and not all_pairs:  # grid ring-search kernels; larger clouds take the tiled all-pairs kernel
             ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=xyz1.device)
             check(L.hf_knn_point_sorted(b, n, m, k, ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), ptr(ws), nbytes, stream_ptr()),

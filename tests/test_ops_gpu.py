@@ -1105,7 +1105,7 @@ def test_oracle_knn(hf, oracle_mod, b, n, m, k):
     if n >= 64:
         x1[:, n // 2:n // 2 + 8] = x1[:, :8]
         x2[:, :4] = x1[:, :4]
-    val, idx = hf.knn_point(k, dev(x1), dev(x2))
+    val, idx = hf.knn_point(k, dev(x1), dev(x2), all_pairs=False)
     ov, oi = oracle_mod.knn_point(k, x1, x2)
     assert np.array_equal(host(idx), oi)
     assert np.array_equal(host(val), ov)
@@ -1143,7 +1143,7 @@ def test_knn_sorted_sweep_matches_all_pairs_scan(hf, oracle_mod, kind):
     if kind == "max_sorted":
         x2[0, :3] = [[1e6, 0, 0], [-1e6, 0, 0], [0, 1e30, 0]]           # queries far outside the data's x range
         x1[0, :4, 0] = [np.inf, -np.inf, np.nan, 3e38]                   # non-finite / huge data coordinates
-    val, idx = hf.knn_point(k, dev(x1), dev(x2))
+    val, idx = hf.knn_point(k, dev(x1), dev(x2), all_pairs=False)
     v2, i2 = hf.knn_point(k, dev(x1), dev(x2), all_pairs=True)
     assert torch.equal(idx, i2) and np.array_equal(host(val), host(v2), equal_nan=True)
     if n <= 1000:
