@@ -165,6 +165,67 @@ __global__ __launch_bounds__(NT) void fps_onchip_kernel(int n, int m, const floa
 }
 
 // ------------------------------------------------------------------------------------------
+// One WAVE per cloud (clouds of at most 512 points: the RoI clouds of the second stage, 800 per batch, 512 -> 128 -> 32 -> 8
+// points; the coarsest encoder levels of the RPN).  A round of the workgroup kernel above is an LDS exchange and a barrier
+// between four or more waves (~5 us per round with eight workgroups per CU: 0.64 ms for 800 x 512 -> 128); a single wave holds
+// all 512 points (8 per lane) and needs neither: the round is the lanes' updates, one DPP arg-max and three v_readlane.  Same
+// arithmetic, same tie rule (k < 512: the smaller k wins; within a lane the slots are in ascending k and the first one wins).
+// ------------------------------------------------------------------------------------------
+constexpr int kFpsWaveMaxPoints = 512;
+constexpr int kFpsWaveThreads = 256;   // four independent clouds per workgroup
+
+template <int PPT>
+__global__ __launch_bounds__(kFpsWaveThreads) void fps_wave_kernel(int b, int n, int m, const float *__restrict__ xyz, int *__restrict__ out)
+{
+    typedef typename FpsVec<PPT>::type vec_t;
+    const int lane = threadIdx.x & 63;
+    const int cloud = blockIdx.x * (kFpsWaveThreads / 64) + (threadIdx.x >> 6);
+    if (cloud >= b) return;   // whole waves leave; nothing below synchronises across waves
+    const float *pts = xyz + static_cast<size_t>(cloud) * n * 3;
+    int *o = out + static_cast<size_t>(cloud) * m;
+    vec_t x, y, z;
+    int td[PPT];  // running min distance as float bits (>= +0: int order == float order); -1 = no point
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = lane + 64 * i;
+        const bool ok = k < n;
+        const int kk = ok ? k : 0;
+        vec_set<PPT>(x, i, pts[kk * 3 + 0]);
+        vec_set<PPT>(y, i, pts[kk * 3 + 1]);
+        vec_set<PPT>(z, i, pts[kk * 3 + 2]);
+        td[i] = ok ? __float_as_int(1e38f) : -1;
+    }
+    float x1 = pts[0], y1 = pts[1], z1 = pts[2];
+    const int mm = m < PPT * 64 ? m : PPT * 64;  // rounds beyond n only repeat point 0 (all distances are 0)
+    if (lane == 0) o[0] = 0;
+    for (int j = 1; j < mm; ++j) {
+        int best = -1, bi = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float dx = vec_get<PPT>(x, i) - x1, dy = vec_get<PPT>(y, i) - y1, dz = vec_get<PPT>(z, i) - z1;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const int sdist = min(__float_as_int(d), td[i]);  // == fminf on non-negative floats
+            td[i] = sdist;
+            if (sdist > best) { best = sdist; bi = i; }  // strict: the first slot (the smaller k) wins
+        }
+        const int wbest = static_cast<int>(wave_max_u32(static_cast<unsigned>(best + 1))) - 1;
+        unsigned long long tied = __ballot(best == wbest);
+        if (__builtin_popcountll(tied) > 1) {   // wave-uniform, rare: exact distance tie between lanes
+            const unsigned key = best == wbest ? fps_tiekey(lane + 64 * bi) : 0xffffffffu;
+            const unsigned kmin = wave_min_u32(key);
+            tied = __ballot(key == kmin);
+        }
+        const int wl = __builtin_ctzll(tied);
+        const int wi = __builtin_amdgcn_readlane(bi, wl);
+        x1 = readlane_f(vec_get<PPT>(x, wi), wl);
+        y1 = readlane_f(vec_get<PPT>(y, wi), wl);
+        z1 = readlane_f(vec_get<PPT>(z, wi), wl);
+        if (lane == 0) o[j] = wl + 64 * wi;
+    }
+    for (int j = mm + lane; j < m; j += 64) o[j] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Bucketed FPS (main path for larger clouds).  Same arithmetic, same winner every round; the
 // difference is which points get touched.
 //
@@ -544,6 +605,16 @@ static int launch_fps_plain_nt(int b, int n, int m, const float *inp, int *out, 
 // kernels against the oracle); nt: workgroup size of the plain kernel (0 = by size)
 static int launch_fps_onchip(int b, int n, int m, const float *inp, int *out, hipStream_t st, int mode = HF_FPS_AUTO, int nt = 0)
 {
+    if (mode == HF_FPS_WAVE || (mode == HF_FPS_AUTO && n <= kFpsWaveMaxPoints)) {
+        if (n > kFpsWaveMaxPoints) return HF_EINVAL;
+        const dim3 grid(div_up(b, kFpsWaveThreads / 64));
+        const int ppt = div_up(n, 64);
+        if (ppt <= 1) hipLaunchKernelGGL((fps_wave_kernel<1>), grid, dim3(kFpsWaveThreads), 0, st, b, n, m, inp, out);
+        else if (ppt <= 2) hipLaunchKernelGGL((fps_wave_kernel<2>), grid, dim3(kFpsWaveThreads), 0, st, b, n, m, inp, out);
+        else if (ppt <= 4) hipLaunchKernelGGL((fps_wave_kernel<4>), grid, dim3(kFpsWaveThreads), 0, st, b, n, m, inp, out);
+        else hipLaunchKernelGGL((fps_wave_kernel<8>), grid, dim3(kFpsWaveThreads), 0, st, b, n, m, inp, out);
+        return launch_status();
+    }
     // bucket pruning pays once there are enough rounds to amortise its prologue
     const bool bucket = mode == 2 || (mode == 0 && n >= 8192 && m >= 256);
     if (bucket) {
@@ -593,10 +664,11 @@ HF_API int hf_farthest_point_sample_variant(int kernel, int threads, int b, int 
                                             hf_stream_t stream)
 {
     if (b < 0 || n <= 0 || m <= 0 || !inp || !out) return HF_EINVAL;
-    if (kernel < HF_FPS_AUTO || kernel > HF_FPS_BUCKET || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
+    if (kernel < HF_FPS_AUTO || kernel > HF_FPS_WAVE || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
         return HF_EINVAL;
     if (b == 0) return HF_OK;
     if (n > kFpsMaxPoints) return hf_farthest_point_sample(b, n, m, inp, temp, out, stream);
+    if (kernel == HF_FPS_WAVE && n > kFpsWaveMaxPoints) return HF_EINVAL;
     if (kernel == HF_FPS_PLAIN && threads != 0 && n > threads * (threads == 1024 ? 16 : 32)) return HF_EINVAL;
     if (kernel == HF_FPS_PLAIN && threads == 256 && n > 256 * 16) return HF_EINVAL;
     return launch_fps_onchip(b, n, m, inp, out, as_stream(stream), kernel, threads);

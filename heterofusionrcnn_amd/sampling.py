@@ -8,7 +8,7 @@ from . import _lib
 from ._lib import check, dev_tensor, ptr, require, stream_ptr
 
 
-FPS_KERNELS = {"auto": 0, "plain": 1, "bucket": 2}   # HF_FPS_* of include/hfops.h
+FPS_KERNELS = {"auto": 0, "plain": 1, "bucket": 2, "wave": 3}   # HF_FPS_* of include/hfops.h
 
 
 def farthest_point_sample(npoint, inp, kernel="auto", threads=0):

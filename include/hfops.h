@@ -59,10 +59,13 @@ int hf_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
 /* The same op with the kernel forced (the tests run every kernel against the oracle): HF_FPS_PLAIN = points and running
  * distances in registers, `threads` = 256 / 512 / 1024 per cloud (0: by size); HF_FPS_BUCKET = the spatially bucketed kernel
  * with exact pruning, `threads` = 1024 (16 waves x 16 buckets) or anything else = 512 (8 waves x 32 buckets, the default);
- * HF_FPS_AUTO = what hf_farthest_point_sample picks (bucketed from 8192 points).  Identical output whatever the choice. */
+ * HF_FPS_WAVE = one wave per cloud, no barrier per round (n <= 512: the RoI clouds of the second stage);
+ * HF_FPS_AUTO = what hf_farthest_point_sample picks (one wave per cloud up to 512 points, bucketed from 8192).  Identical output
+ * whatever the choice. */
 #define HF_FPS_AUTO 0
 #define HF_FPS_PLAIN 1
 #define HF_FPS_BUCKET 2
+#define HF_FPS_WAVE 3
 int hf_farthest_point_sample_variant(int kernel, int threads, int b, int n, int m, const float *inp, float *temp, int *out,
                                      hf_stream_t stream);
 size_t hf_fps_workspace(int b, int n);

@@ -77,9 +77,28 @@ def _fps_both_kernels(hf, m, xyz_dev):
     for mode, nt in (("plain", 0), ("bucket", 512), ("bucket", 1024)):     # 8 waves x 32 buckets / 16 waves x 16 buckets
         outs.append(hf.farthest_point_sample(m, xyz_dev, kernel=mode, threads=nt))
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "plain and bucketed FPS disagree"
+    if xyz_dev.shape[1] <= 512:       # one wave per cloud (what "auto" picks at this size)
+        assert torch.equal(outs[0], hf.farthest_point_sample(m, xyz_dev, kernel="wave")), "plain and one-wave FPS disagree"
     auto = hf.farthest_point_sample(m, xyz_dev)
     assert torch.equal(auto, outs[0])
     return auto
+
+
+@pytest.mark.parametrize("b,n,m", [(37, 512, 128), (5, 128, 32), (9, 32, 8), (3, 500, 600), (2, 64, 64), (4, 65, 10), (1, 1, 3)])
+def test_fps_one_wave_per_cloud_against_oracle(hf, oracle_mod, b, n, m):
+    """fps_wave_kernel (clouds of at most 512 points: the second stage's RoI clouds, rcnn_multiclass.config:157-186) against the
+    oracle, with the cyclic padding of pc_crop_and_sample in the data (exact duplicates -> exact distance ties) and more samples than
+    points"""
+    rng = np.random.default_rng(b * 1000 + n)
+    x = (rng.normal(0, 1, (b, n, 3)) * np.array([1.5, 0.8, 2.5])).astype(np.float32)
+    if n >= 8:
+        x[:, n // 2:] = x[:, :n - n // 2]          # the second half repeats the first: every distance has a tie
+        x[0, :4] = x[0, 4:8]
+    want = oracle_mod.farthest_point_sample(m, x)
+    got = hf.farthest_point_sample(m, dev(x), kernel="wave")
+    assert np.array_equal(host(got), want)
+    assert np.array_equal(host(hf.farthest_point_sample(m, dev(x))), want)                 # auto
+    assert np.array_equal(host(hf.farthest_point_sample(m, dev(x), kernel="plain")), want)
 
 
 def test_golden_fps_gather(hf):
@@ -1408,7 +1427,8 @@ def test_fuzz_all_ops_against_oracle(hf, oracle_mod):
         # FPS on every kernel
         mm = int(min(n + 3, rng.choice([1, 2, 17, 128, 700])))
         want = oracle_mod.farthest_point_sample(mm, x1)
-        variants = [("plain", 1024), ("plain", 512), ("bucket", 0), ("bucket", 512), ("bucket", 1024)] + ([("plain", 256)] if n <= 4096 else [])
+        variants = ([("plain", 1024), ("plain", 512), ("bucket", 0), ("bucket", 512), ("bucket", 1024)] + ([("plain", 256)] if n <= 4096 else []) +
+                    ([("wave", 0)] if n <= 512 else []))
         for mode, nt in variants:
             got = hf.farthest_point_sample(mm, dev(x1), kernel=mode, threads=nt)
             assert np.array_equal(host(got), want), (trial, mode, nt, b, n, mm)
