@@ -244,10 +244,10 @@ def knn_point(k, xyz1, xyz2, all_pairs=None, dense=False):
         idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
         L = _lib.lib()
         nbytes = L.hf_knn_workspace(b, n)
-        # tiny problems (the RCNN's RoI clouds below its first layer: 512 x 128, 128 x 32, 32 x 8 per RoI, 800 RoIs) are faster on
-        # the all-pairs kernel than through binning + ring search (284 / 183 / 58 us against 421 / 332 / 149;
-        # scripts/probes/knn_small_timing.py); both kernels rank (q - p)^2 with ties to the lower index: same result
-        all_pairs = (n * m <= 65536) if all_pairs is None else bool(all_pairs)
+        # small clouds (the RCNN's RoI clouds: 512 x 512, 512 x 128, 128 x 32, 32 x 8 per RoI, 800 RoIs) are faster on the
+        # all-pairs entry point -- its register-list kernel for k = 4 / 8 / 12 / 16 -- than through binning + ring search
+        # (scripts/probes/knn_small_timing.py); both rank (q - p)^2 with ties to the lower index: same result
+        all_pairs = (n * m <= 65536 or (n <= 1024 and k in (4, 8, 12, 16))) if all_pairs is None else bool(all_pairs)
         if nbytes and not all_pairs:  # grid ring-search kernels; larger clouds take the tiled all-pairs kernel
             ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=xyz1.device)
             check(L.hf_knn_point_sorted(b, n, m, k, ptr(xyz1), ptr(xyz2), ptr(val), ptr(idx), ptr(ws), nbytes, stream_ptr()),
