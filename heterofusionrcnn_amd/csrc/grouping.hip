@@ -744,6 +744,105 @@ __global__ __launch_bounds__(kKnnThreads) void knn_grid_kernel(int n, int m, int
     }
 }
 
+// The same search for k = 3 / 4 / 8 / 12 / 16 (three_nn and every neighbourhood size of the shipped configs) with the list in
+// REGISTERS and the memory round trips batched.  The kernel above walks a cell point by point -- one dependent 16-byte load per
+// candidate, plus two bound loads per cell -- ~100 serial round trips per query at k = 8: it is latency-bound (221 us for 8 x 16384
+// queries on 4096 points).  Here: the cells of one grid ROW are consecutive in the sorted array, so the top and the bottom row of a
+// ring are each ONE contiguous range (two bound loads, all four issued together); a range is scanned four candidates per trip (four
+// loads in flight); the list is K (distance, index) register pairs, sorted insertion as K select pairs.  Same candidates, same
+// (distance, index) order, same stop rule: same output.
+template <int K>
+__global__ __launch_bounds__(kKnnThreads) void knn_grid_reg_kernel(int n, int m, int g, const float *__restrict__ xyz2,
+                                                                   void *__restrict__ workspace, float *__restrict__ val,
+                                                                   int *__restrict__ idx)
+{
+    const int t = threadIdx.x, bb = blockIdx.y;
+    const int j = blockIdx.x * kKnnThreads + t;
+    if (j >= m) return;
+    const KnnWs w = knn_ws(workspace, bb, n, g);
+    const float *q = xyz2 + (static_cast<size_t>(bb) * m + j) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+    auto offer = [&](const float4 &p) __attribute__((always_inline)) {
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const int ci = __float_as_int(p.w);
+        // an infinite distance never enters the list (the tiled kernel's strict `d < worst` against its +inf sentinel)
+        if (d < bd[K - 1] || (d == bd[K - 1] && ci < bi[K - 1] && d < INFINITY)) {
+            float cd = d;
+            int cc = ci;
+            bool shift = false;   // from the insertion point on every entry moves down one place
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                const bool lt = shift || cd < bd[s] || (cd == bd[s] && cc < bi[s]);
+                shift = lt;
+                const float od = bd[s];
+                const int oi = bi[s];
+                bd[s] = lt ? cd : od; bi[s] = lt ? cc : oi;
+                cd = lt ? od : cd; cc = lt ? oi : cc;
+            }
+        }
+    };
+    // sorted entries i0 .. i1-1, four per trip (past the end: the last entry again, not offered)
+    auto scan = [&](int i0, int i1) __attribute__((always_inline)) {   // (outlined, the lists would live in scratch)
+        for (int i = i0; i < i1; i += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = w.pts[min(i + u, i1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u < i1) offer(p[u]);
+        }
+    };
+    const float amin = w.params[0], sa = w.params[1], bmin = w.params[2], sb = w.params[3];
+    const float wa = w.params[4], wb = w.params[5];
+    const int axa = __float_as_int(w.params[6]), axb = __float_as_int(w.params[7]);
+    const float qa = axa == 0 ? qx : (axa == 1 ? qy : qz), qb = axb == 0 ? qx : (axb == 1 ? qy : qz);
+    const int ca = knn_cell1(qa, amin, sa, g), cb = knn_cell1(qb, bmin, sb, g);
+    const float margin_a = 1e-3f * wa, margin_b = 1e-3f * wb;
+    for (int ring = 0; ring < g; ++ring) {
+        const int a0 = ca - ring, a1 = ca + ring, b0 = cb - ring, b1 = cb + ring;
+        const int alo = a0 < 0 ? 0 : a0, ahi = a1 > g - 1 ? g - 1 : a1;
+        if (ring == 0) {
+            const int c = cb * g + ca;
+            scan(w.cellstart[c], w.cellstart[c + 1]);
+        } else {
+            // top and bottom rows of the ring: one contiguous range each (their four bounds requested together)
+            const bool top = b0 >= 0, bot = b1 <= g - 1;
+            const int t0 = top ? w.cellstart[b0 * g + alo] : 0, t1 = top ? w.cellstart[b0 * g + ahi + 1] : 0;
+            const int u0 = bot ? w.cellstart[b1 * g + alo] : 0, u1 = bot ? w.cellstart[b1 * g + ahi + 1] : 0;
+            scan(t0, t1);
+            scan(u0, u1);
+            // the two side columns without their corners: single cells, the bounds of a row's pair requested together
+            for (int b = (b0 + 1 < 0 ? 0 : b0 + 1); b <= (b1 - 1 > g - 1 ? g - 1 : b1 - 1); ++b) {
+                const bool left = a0 >= 0, right = a1 <= g - 1;
+                const int l0 = left ? w.cellstart[b * g + a0] : 0, l1 = left ? w.cellstart[b * g + a0 + 1] : 0;
+                const int r0 = right ? w.cellstart[b * g + a1] : 0, r1 = right ? w.cellstart[b * g + a1 + 1] : 0;
+                scan(l0, l1);
+                scan(r0, r1);
+            }
+        }
+        // distance from the query to the nearest side of the visited block that still has cells beyond it
+        float gap = INFINITY;
+        if (a0 > 0) gap = fminf(gap, (qa - (amin + static_cast<float>(a0) * wa)) - margin_a);
+        if (a1 < g - 1) gap = fminf(gap, ((amin + static_cast<float>(a1 + 1) * wa) - qa) - margin_a);
+        if (b0 > 0) gap = fminf(gap, (qb - (bmin + static_cast<float>(b0) * wb)) - margin_b);
+        if (b1 < g - 1) gap = fminf(gap, ((bmin + static_cast<float>(b1 + 1) * wb) - qb) - margin_b);
+        if (gap == INFINITY) break;                       // the block covers the whole grid
+        if (gap > 0.0f && gap * gap > bd[K - 1]) break;   // nothing outside the block can enter the list
+    }
+    float *ov = val + (static_cast<size_t>(bb) * m + j) * K;
+    int *oi = idx + (static_cast<size_t>(bb) * m + j) * K;
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        ov[s] = bd[s];
+        oi[s] = bi[s] == 0x7fffffff ? 0 : bi[s];  // an unfilled slot (all remaining distances infinite / NaN): index 0, as above
+    }
+}
+
 static int knn_grid_for(int n)
 {
     int g = 4;
@@ -972,6 +1071,19 @@ int launch_knn_grid(int b, int n, int m, int k, const float *data, const float *
     if (lds > 150 * 1024 || b > 65535 || reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return HF_EINVAL;  // k <= 75
     const int g = knn_grid_for(n);
     hipLaunchKernelGGL(knn_bin_kernel, dim3(b), dim3(kKnnBinThreads), 0, st, n, g, data, workspace);
+    {
+        const dim3 grid(div_up(m, kKnnThreads), b);
+#define HF_KNN_REG(KK) hipLaunchKernelGGL((knn_grid_reg_kernel<KK>), grid, dim3(kKnnThreads), 0, st, n, m, g, queries, workspace, val, idx)
+        switch (k) {   // the register-list kernel for three_nn and the shipped neighbourhood sizes
+        case 3: HF_KNN_REG(3); return launch_status();
+        case 4: HF_KNN_REG(4); return launch_status();
+        case 8: HF_KNN_REG(8); return launch_status();
+        case 12: HF_KNN_REG(12); return launch_status();
+        case 16: HF_KNN_REG(16); return launch_status();
+        default: break;
+        }
+#undef HF_KNN_REG
+    }
     if (const int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&knn_grid_kernel), lds); lrc != HF_OK) return lrc;
     hipLaunchKernelGGL(knn_grid_kernel, dim3(div_up(m, kKnnThreads), b), dim3(kKnnThreads), lds, st, n, m, k, g, queries,
                        workspace, val, idx);
