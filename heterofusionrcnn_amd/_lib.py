@@ -96,6 +96,7 @@ _SIGNATURES = {
     "hf_lift_elu_bn_fwd": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp,
                            _vp, _sz, _vp],
     "hf_lift_elu_fwd_eval": [ctypes.c_longlong, _i, _i] + [_vp] * 8 + [_vp, _sz, _vp],
+    "hf_lift_elu_fwd_eval_bn": [ctypes.c_longlong, _i, _i] + [_vp] * 12 + [_vp, _sz, _vp],
     "hf_lift_elu_bn_bwd_workspace": [ctypes.c_longlong, _i, _i],
     "hf_lift_elu_bn_bwd": [ctypes.c_longlong, _i, _i] + [_vp] * 12 + [_vp, _sz, _vp],
     "hf_project_gather": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -657,12 +657,26 @@ template <int NT>
 __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2))) void lift_linear_fwd_kernel(
     long long rows, int c0, int cout, long long ntiles, const float *__restrict__ x3, const float *__restrict__ w0,
     const float *__restrict__ gamma0, const float *__restrict__ beta0, const float *__restrict__ mean0,
-    const float *__restrict__ invstd0, const float *__restrict__ W, float *__restrict__ Z, float *__restrict__ partial)
+    const float *__restrict__ invstd0, const float *__restrict__ W, float *__restrict__ Z, float *__restrict__ partial,
+    const float *__restrict__ gamma1, const float *__restrict__ beta1, const float *__restrict__ mean1, const float *__restrict__ invstd1)
 {
     __shared__ float As[kFwdRows * kFwdLS];
     __shared__ float Bs[NT * 32 * kFwdLS];
     __shared__ float red[4][NT * 32][2];
     __shared__ LiftTab T;
+    // inference with the second layer's running statistics given (hf_lift_elu_fwd_eval_bn): the epilogue stores
+    // gamma1 * invstd1 * (elu(z1) - mean1) + beta1 instead of z1 -- the normalisation pass of that layer (a read and a write of the
+    // rows x C1 tensor: 0.32 ms for the second stage's 1.6 M x 128 lifting layer) disappears
+    const bool out_bn = gamma1 != nullptr;
+    float oa[NT], ob[NT], om[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 32 + (threadIdx.x & 31);
+        const bool okc = out_bn && col < cout;
+        oa[nt] = okc ? gamma1[col] * invstd1[col] : 0.f;
+        ob[nt] = okc ? beta1[col] : 0.f;
+        om[nt] = okc ? mean1[col] : 0.f;
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     lift_tab_load(T, c0, w0, gamma0, beta0, mean0, invstd0);
     __syncthreads();
@@ -735,8 +749,8 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(2)
                 const long long row = row0 + 32 * wave + 8 * (g >> 2) + 4 * (lane >> 5) + (g & 3);
                 const float v = acc[nt][g];
                 if (col < cout && row < rows) {
-                    Z[row * cout + col] = v;
                     const float sv = lift_elu(v);   // 32 expm1f per lane and tile cost as much as the tile's MFMAs; |difference| <= 6e-8
+                    Z[row * cout + col] = out_bn ? oa[nt] * (sv - om[nt]) + ob[nt] : v;   // the apply pass's own expression
                     s1[nt] += sv;
                     s2[nt] += sv * sv;
                 }
@@ -1254,6 +1268,8 @@ HF_API int hf_linear_elu_bn_bwd(long long rows, int cout, int cin, const float *
                               p_gamma, p_beta, p_mean, p_invstd, p_dgamma, p_dbeta, workspace, workspace_bytes, stream, 1);
 }
 
+static const float *const kNoF = nullptr;
+
 HF_API size_t hf_lift_elu_bn_fwd_workspace(int c0, int c1)
 {
     if (c0 <= 0 || c1 <= 0) return 0;
@@ -1284,7 +1300,7 @@ HF_API int hf_lift_elu_bn_fwd(long long rows, int c0, int c1, const float *x3, c
 #define HF_LIFT_FWD(N)                                                                                                  \
     case N:                                                                                                             \
         hipLaunchKernelGGL((lift_linear_fwd_kernel<N>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, c0, c1, ntiles, x3, w0,  \
-                           gamma0, beta0, mean0, invstd0, w1, z1, partial);                                             \
+                           gamma0, beta0, mean0, invstd0, w1, z1, partial, kNoF, kNoF, kNoF, kNoF);                     \
         break
     switch (nt) {
         HF_LIFT_FWD(1); HF_LIFT_FWD(2); HF_LIFT_FWD(3); HF_LIFT_FWD(4); HF_LIFT_FWD(5); HF_LIFT_FWD(6); HF_LIFT_FWD(7); HF_LIFT_FWD(8);
@@ -1297,9 +1313,10 @@ HF_API int hf_lift_elu_bn_fwd(long long rows, int c0, int c1, const float *x3, c
 
 // inference: the first layer normalised with GIVEN statistics (its running estimates), no statistics pass; the second GEMM's batch
 // statistics land in the workspace and are ignored
-HF_API int hf_lift_elu_fwd_eval(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
-                                const float *mean0, const float *invstd0, const float *w1, float *z1, void *workspace,
-                                size_t workspace_bytes, hf_stream_t stream)
+static int lift_elu_fwd_eval_impl(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                                  const float *mean0, const float *invstd0, const float *w1, const float *gamma1, const float *beta1,
+                                  const float *mean1, const float *invstd1, float *z1, void *workspace, size_t workspace_bytes,
+                                  hf_stream_t stream)
 {
     if (rows <= 0 || c0 <= 0 || c0 > kLiftMaxC || c0 % 4 != 0 || c1 <= 0 || c1 > 256 || !x3 || !w0 || !gamma0 || !beta0 || !mean0 ||
         !invstd0 || !w1 || !z1 || reinterpret_cast<uintptr_t>(w1) % 16 != 0)
@@ -1313,7 +1330,7 @@ HF_API int hf_lift_elu_fwd_eval(long long rows, int c0, int c1, const float *x3,
 #define HF_LIFT_FWD(N)                                                                                                  \
     case N:                                                                                                             \
         hipLaunchKernelGGL((lift_linear_fwd_kernel<N>), dim3(nblk), dim3(kGemmThreads), 0, st, rows, c0, c1, ntiles, x3, w0,  \
-                           gamma0, beta0, mean0, invstd0, w1, z1, partial);                                             \
+                           gamma0, beta0, mean0, invstd0, w1, z1, partial, gamma1, beta1, mean1, invstd1);              \
         break
     switch (nt) {
         HF_LIFT_FWD(1); HF_LIFT_FWD(2); HF_LIFT_FWD(3); HF_LIFT_FWD(4); HF_LIFT_FWD(5); HF_LIFT_FWD(6); HF_LIFT_FWD(7); HF_LIFT_FWD(8);
@@ -1321,6 +1338,24 @@ HF_API int hf_lift_elu_fwd_eval(long long rows, int c0, int c1, const float *x3,
     }
 #undef HF_LIFT_FWD
     return launch_status();
+}
+
+HF_API int hf_lift_elu_fwd_eval(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                                const float *mean0, const float *invstd0, const float *w1, float *z1, void *workspace,
+                                size_t workspace_bytes, hf_stream_t stream)
+{
+    return lift_elu_fwd_eval_impl(rows, c0, c1, x3, w0, gamma0, beta0, mean0, invstd0, w1, nullptr, nullptr, nullptr, nullptr, z1, workspace,
+                                  workspace_bytes, stream);
+}
+
+HF_API int hf_lift_elu_fwd_eval_bn(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                                   const float *mean0, const float *invstd0, const float *w1, const float *gamma1, const float *beta1,
+                                   const float *mean1, const float *invstd1, float *y1, void *workspace, size_t workspace_bytes,
+                                   hf_stream_t stream)
+{
+    if (!gamma1 || !beta1 || !mean1 || !invstd1) return HF_EINVAL;
+    return lift_elu_fwd_eval_impl(rows, c0, c1, x3, w0, gamma0, beta0, mean0, invstd0, w1, gamma1, beta1, mean1, invstd1, y1, workspace,
+                                  workspace_bytes, stream);
 }
 
 HF_API size_t hf_lift_elu_bn_bwd_workspace(long long rows, int c0, int c1)

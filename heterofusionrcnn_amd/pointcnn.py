@@ -186,9 +186,11 @@ def _lift_chain_eval(d0, d1, x):
     nbytes = L.hf_lift_elu_bn_fwd_workspace(c0, c1)
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
     w0, w1 = d0.linear.weight.contiguous(), d1.linear.weight.contiguous()
-    check(L.hf_lift_elu_fwd_eval(rows, c0, c1, ptr(x2), ptr(w0), ptr(bn0.weight), ptr(bn0.bias), ptr(bn0.running_mean), ptr(bn0.eval_invstd()),
-                                 ptr(w1), ptr(z1), ptr(ws), nbytes, stream_ptr()), "lift_elu_fwd_eval")
-    return bn1(z1).reshape(*x.shape[:-1], c1)          # eval-mode BatchNormReLU: a (elu(z1) - running_mean) + beta
+    # the second layer's a (elu(z1) - running_mean) + beta leaves the GEMM's epilogue: no normalisation pass
+    check(L.hf_lift_elu_fwd_eval_bn(rows, c0, c1, ptr(x2), ptr(w0), ptr(bn0.weight), ptr(bn0.bias), ptr(bn0.running_mean),
+                                    ptr(bn0.eval_invstd()), ptr(w1), ptr(bn1.weight), ptr(bn1.bias), ptr(bn1.running_mean),
+                                    ptr(bn1.eval_invstd()), ptr(z1), ptr(ws), nbytes, stream_ptr()), "lift_elu_fwd_eval_bn")
+    return z1.reshape(*x.shape[:-1], c1)
 
 
 def dense_chain(d0, d1, x):

@@ -378,6 +378,12 @@ int hf_lift_elu_bn_fwd(long long rows, int c0, int c1, const float *x3, const fl
 int hf_lift_elu_fwd_eval(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
                          const float *mean0, const float *invstd0, const float *w1, float *z1, void *workspace, size_t workspace_bytes,
                          hf_stream_t stream);
+/* the same with the SECOND layer's inference constants given too: y1 = gamma1 * invstd1 * (elu(z1) - mean1) + beta1 leaves the GEMM's
+ * epilogue, the normalisation pass of that layer does not run (two-stage inference: the lifting layers of the RoI clouds) */
+int hf_lift_elu_fwd_eval_bn(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
+                            const float *mean0, const float *invstd0, const float *w1, const float *gamma1, const float *beta1,
+                            const float *mean1, const float *invstd1, float *y1, void *workspace, size_t workspace_bytes,
+                            hf_stream_t stream);
 size_t hf_lift_elu_bn_bwd_workspace(long long rows, int c0, int c1);
 int hf_lift_elu_bn_bwd(long long rows, int c0, int c1, const float *x3, const float *w0, const float *gamma0, const float *beta0,
                        const float *mean0, const float *invstd0, const float *dz1, const float *w1_t, float *grad_w0_t,

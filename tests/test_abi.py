@@ -182,3 +182,7 @@ def test_bn_dropout_and_narrow_linear_argument_checks():
     assert L.hf_narrow_linear_dx(4096, 256, 5, one, one, one, None) == _lib.HF_EINVAL                               # at most four outputs
     assert L.hf_narrow_linear_dx(4096, 256, 2, one, None, one, None) == _lib.HF_EINVAL
     assert L.hf_narrow_linear_dx(0, 256, 2, one, one, one, None) == _lib.HF_EINVAL
+    # inference lifting chain with the second layer's constants: all four of them, and the workspace of the training form
+    args = (4096, 64, 64, one, one, one, one, one, one, one)
+    assert L.hf_lift_elu_fwd_eval_bn(*args, one, one, one, None, one, one, big, None) == _lib.HF_EINVAL
+    assert L.hf_lift_elu_fwd_eval_bn(*args, one, one, one, one, one, one, 16, None) == _lib.HF_EWORKSPACE
