@@ -522,9 +522,9 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="override the per-GPU batch (default: 8, or 8 / N with --scaling strong)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the step kernel by kernel (DistributedDataParallel for N > 1) "
                                                             "instead of replaying the captured hipGraph")
-    ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph whatever the batch (default: the graph below "
-                                                         "8 frames per GPU, where launches bound the step; kernel-by-kernel at 8, "
-                                                         "where the device does and replay measured 3 %% slower)")
+    ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph whatever the batch and workload (default: "
+                                                         "rpn_multiclass always replays; the other workloads below 8 frames per "
+                                                         "GPU, where launches bound the step)")
     ap.add_argument("--optimizer", choices=("hf", "torch"), default="hf",
                     help="hf: optim.MultiTensorAdam (every parameter tensor in one launch, csrc/optim.hip, torch.optim.Adam's "
                          "arithmetic); torch: torch.optim.Adam(fused=True)")
@@ -729,7 +729,10 @@ def main():
 
         from heterofusionrcnn_amd.graph_step import TrainStep, broadcast_parameters
         from heterofusionrcnn_amd.pipeline import GeometryPrefetcher, choose_group
-        use_graph = (args.graph or per_gpu < B) and not args.no_graph
+        # the PointCNN RPN step is replayed from its captured hipGraphs whatever the batch: at 8 frames the device bounds the step
+        # either way (27.0 ms replayed, 27.0-27.2 enqueued), but enqueueing costs the host 21.6 ms of those 27 -- a slower or busier
+        # host would make the enqueued form launch-bound; the enqueued figure is reported under extra
+        use_graph = (args.graph or per_gpu < B or (args.workload == "rpn_multiclass" and not args.with_vgg)) and not args.no_graph
         group = args.prefetch_group or choose_group(args.steps)
         prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth, group=group)
         lr = dp.scaled_lr(1e-3, world)                                   # optimizer_builder.py:105
