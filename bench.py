@@ -729,10 +729,11 @@ def main():
 
         from heterofusionrcnn_amd.graph_step import TrainStep, broadcast_parameters
         from heterofusionrcnn_amd.pipeline import GeometryPrefetcher, choose_group
-        # the PointCNN RPN step is replayed from its captured hipGraphs whatever the batch: at 8 frames the device bounds the step
+        # one rank: the PointCNN RPN step is replayed from its captured hipGraphs whatever the batch (several ranks at 8 frames per
+        # rank = the fixed-per-rank-batch mode stay on DistributedDataParallel): at 8 frames the device bounds the step
         # either way (27.0 ms replayed, 27.0-27.2 enqueued), but enqueueing costs the host 21.6 ms of those 27 -- a slower or busier
         # host would make the enqueued form launch-bound; the enqueued figure is reported under extra
-        use_graph = (args.graph or per_gpu < B or (args.workload == "rpn_multiclass" and not args.with_vgg)) and not args.no_graph
+        use_graph = (args.graph or per_gpu < B or (args.workload == "rpn_multiclass" and not args.with_vgg and world == 1)) and not args.no_graph
         group = args.prefetch_group or choose_group(args.steps)
         prefetch = None if args.no_prefetch else GeometryPrefetcher(model.geometry, depth=args.prefetch_depth, group=group)
         lr = dp.scaled_lr(1e-3, world)                                   # optimizer_builder.py:105
