@@ -55,6 +55,17 @@ template <> struct VecT<1> { typedef float type; };
 
 template <int VEC>
 __device__ __forceinline__ typename VecT<VEC>::type ldv(const float *p) { return *reinterpret_cast<const typename VecT<VEC>::type *>(p); }
+// NT: a streaming load (a template parameter: as a run-time select between two loads of one address the compiler merged them
+// into a plain load).  The passes over tensors that cannot stay in the 256 MB Infinity Cache between the pass that
+// brings them in and the pass that reads them again (forward: one tensor above ~200 MB; backward: x and dy together) read 20-25 %
+// faster when their loads do not allocate there (1 M x 64: forward 168 -> 136 us, backward 273 -> 223 us); smaller tensors ARE
+// re-read from the cache by the second pass and lose 5 % with streaming loads (scripts/probes/bn_stream_timing.py)
+template <int VEC, bool NT>
+__device__ __forceinline__ typename VecT<VEC>::type ldv_s(const float *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const typename VecT<VEC>::type *>(p));
+    else return ldv<VEC>(p);
+}
 template <int VEC>
 __device__ __forceinline__ void stv(float *p, typename VecT<VEC>::type v) { *reinterpret_cast<typename VecT<VEC>::type *>(p) = v; }
 template <int VEC> __device__ __forceinline__ float vget(const typename VecT<VEC>::type &v, int i) { return v[i]; }
@@ -137,7 +148,7 @@ __device__ __forceinline__ void drop_multipliers(unsigned long long vidx, unsign
 // A thread's rows are rsub, rsub + rpb, ... < local (rows of the block); operands are addressed as a uniform block base plus a 32-bit
 // element offset (bn_geom keeps rows_per_block x row stride below 2^31).
 // partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over the block's rows
-template <int VEC, bool ELU>
+template <int VEC, bool ELU, bool NT>
 __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                 const float *__restrict__ x, float *__restrict__ partial)
 {
@@ -161,11 +172,11 @@ __global__ void bn_stats_kernel(long long rows, int c, int cv, int rpb, long lon
     for (; row + (kBnUnroll - 1) * rpb < local; row += kBnUnroll * rpb, ox += kBnUnroll * sx) {
         V v[kBnUnroll];
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) v[u] = ldv<VEC>(bx + ox + u * sx);
+        for (int u = 0; u < kBnUnroll; ++u) v[u] = ldv_s<VEC, NT>(bx + ox + u * sx);
 #pragma unroll
         for (int u = 0; u < kBnUnroll; ++u) add(v[u]);
     }
-    for (; row < local; row += rpb, ox += sx) add(ldv<VEC>(bx + ox));
+    for (; row < local; row += rpb, ox += sx) add(ldv_s<VEC, NT>(bx + ox));
     reduce_rows<VEC>(s, q, cv, rpb, cvec, rsub, smem);
     if (rsub == 0) {
         // partial[which][channel][block]: the finalize kernel reads one channel's partials contiguously
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(long long rows, 
 }
 
 // y = relu?(gamma*invstd*(x-mean) + beta)
-template <int VEC, bool ELU, bool DROP>
+template <int VEC, bool ELU, bool DROP, bool NT>
 __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                 const float *__restrict__ x, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, const float *__restrict__ mean,
@@ -309,15 +320,15 @@ __global__ void bn_apply_kernel(long long rows, int c, int cv, int rpb, long lon
     for (; row + (kBnUnroll - 1) * rpb < local; row += kBnUnroll * rpb, ox += kBnUnroll * sx, oy += kBnUnroll * sy) {
         V v[kBnUnroll];
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) v[u] = ldv<VEC>(bx + ox + u * sx);
+        for (int u = 0; u < kBnUnroll; ++u) v[u] = ldv_s<VEC, NT>(bx + ox + u * sx);
 #pragma unroll
         for (int u = 0; u < kBnUnroll; ++u) stv<VEC>(by + oy + u * sy, one(v[u], row + u * rpb));
     }
-    for (; row < local; row += rpb, ox += sx, oy += sy) stv<VEC>(by + oy, one(ldv<VEC>(bx + ox), row));
+    for (; row < local; row += rpb, ox += sx, oy += sy) stv<VEC>(by + oy, one(ldv_s<VEC, NT>(bx + ox), row));
 }
 
 // partial[blk][0][c] = sum dh, partial[blk][1][c] = sum dh*xhat  (dh = dy masked by the ReLU of a*x+b)
-template <int VEC, bool ELU, bool DROP>
+template <int VEC, bool ELU, bool DROP, bool NT>
 __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                      const float *__restrict__ x, const float *__restrict__ dy,
                                      const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -362,11 +373,11 @@ __global__ void bn_bwd_reduce_kernel(long long rows, int c, int cv, int rpb, lon
     for (; row + (kBnUnroll - 1) * rpb < local; row += kBnUnroll * rpb, ox += kBnUnroll * sx, og += kBnUnroll * sg) {
         V v[kBnUnroll], g[kBnUnroll];
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) { v[u] = ldv<VEC>(bx + ox + u * sx); g[u] = ldv<VEC>(bg + og + u * sg); }
+        for (int u = 0; u < kBnUnroll; ++u) { v[u] = ldv_s<VEC, NT>(bx + ox + u * sx); g[u] = ldv_s<VEC, NT>(bg + og + u * sg); }
 #pragma unroll
         for (int u = 0; u < kBnUnroll; ++u) add(v[u], g[u], row + u * rpb);
     }
-    for (; row < local; row += rpb, ox += sx, og += sg) add(ldv<VEC>(bx + ox), ldv<VEC>(bg + og), row);
+    for (; row < local; row += rpb, ox += sx, og += sg) add(ldv_s<VEC, NT>(bx + ox), ldv_s<VEC, NT>(bg + og), row);
     reduce_rows<VEC>(s1, s2, cv, rpb, cvec, rsub, smem);
     if (rsub == 0) {
 #pragma unroll
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int c, int nblk, c
 }
 
 // dx = gamma*invstd*(dh - dbeta/R - xhat*dgamma/R)
-template <int VEC, bool ELU, bool DROP>
+template <int VEC, bool ELU, bool DROP, bool NT>
 __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long long rows_per_block,
                                  const float *__restrict__ x, const float *__restrict__ dy,
                                  const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -445,11 +456,11 @@ __global__ void bn_bwd_dx_kernel(long long rows, int c, int cv, int rpb, long lo
     for (; row + (kBnUnroll - 1) * rpb < local; row += kBnUnroll * rpb, ox += kBnUnroll * sx, og += kBnUnroll * sg) {
         V v[kBnUnroll], g[kBnUnroll];
 #pragma unroll
-        for (int u = 0; u < kBnUnroll; ++u) { v[u] = ldv<VEC>(bx + ox + u * sx); g[u] = ldv<VEC>(bg + og + u * sg); }
+        for (int u = 0; u < kBnUnroll; ++u) { v[u] = ldv_s<VEC, NT>(bx + ox + u * sx); g[u] = ldv_s<VEC, NT>(bg + og + u * sg); }
 #pragma unroll
         for (int u = 0; u < kBnUnroll; ++u) stv<VEC>(bo + ox + u * sx, one(v[u], g[u], row + u * rpb));
     }
-    for (; row < local; row += rpb, ox += sx, og += sg) stv<VEC>(bo + ox, one(ldv<VEC>(bx + ox), ldv<VEC>(bg + og), row));
+    for (; row < local; row += rpb, ox += sx, og += sg) stv<VEC>(bo + ox, one(ldv_s<VEC, NT>(bx + ox), ldv_s<VEC, NT>(bg + og), row));
     if (colsum_partial) {  // column sums of dx = the bias gradient of the Linear that produced x
         reduce_rows<VEC>(cs, unused, cv, rpb, cvec, rsub, smem);
         if (rsub == 0) {
@@ -895,62 +906,80 @@ static void bn_dispatch(const BnGeom &g, bool elu, bool drop, A... a)
 
 static const BnDrop kNoDrop = { nullptr, 0u, 1.0f };
 
-static void launch_bn_stats(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, float *partial, bool elu)
+static void launch_bn_stats(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, float *partial, bool elu, int nt)
 {
     const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-#define HF_BN_L(V, E) hipLaunchKernelGGL((bn_stats_kernel<V, E>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, partial)
-    if (g.vec == 4) { if (elu) HF_BN_L(4, true); else HF_BN_L(4, false); }
-    else { if (elu) HF_BN_L(1, true); else HF_BN_L(1, false); }
+#define HF_BN_L(V, E, N) hipLaunchKernelGGL((bn_stats_kernel<V, E, N>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, partial)
+    if (g.vec == 4 && nt) { if (elu) HF_BN_L(4, true, true); else HF_BN_L(4, false, true); }   // streaming loads: 16-byte form only
+    else if (g.vec == 4) { if (elu) HF_BN_L(4, true, false); else HF_BN_L(4, false, false); }
+    else { if (elu) HF_BN_L(1, true, false); else HF_BN_L(1, false, false); }
 #undef HF_BN_L
 }
 
 template <int V, bool E, bool D> struct BnApplyL {
     static void go(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *gamma, const float *beta,
-                   const float *mean, const float *invstd, int relu, float *y, long long ldy, BnDrop drop)
+                   const float *mean, const float *invstd, int relu, float *y, long long ldy, BnDrop drop, int nt)
     {
-        hipLaunchKernelGGL((bn_apply_kernel<V, E, D>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, gamma,
+        if constexpr (V == 4 && !D) {
+            if (nt) { hipLaunchKernelGGL((bn_apply_kernel<4, E, false, true>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, gamma,
+                           beta, mean, invstd, relu, y, ldy, drop); return; }
+        }
+        hipLaunchKernelGGL((bn_apply_kernel<V, E, D, false>), dim3(g.nblk), dim3(g.threads), 0, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, gamma,
                            beta, mean, invstd, relu, y, ldy, drop);
     }
 };
 static void launch_bn_apply(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *gamma, const float *beta,
-                            const float *mean, const float *invstd, int relu, float *y, long long ldy, BnDrop drop = kNoDrop)
+                            const float *mean, const float *invstd, int relu, float *y, long long ldy, int nt, BnDrop drop = kNoDrop)
 {
-    bn_dispatch<BnApplyL>(g, (relu & kBnEluIn) != 0, drop.seed != nullptr, g, st, rows, c, x, gamma, beta, mean, invstd, relu, y, ldy, drop);
+    bn_dispatch<BnApplyL>(g, (relu & kBnEluIn) != 0, drop.seed != nullptr, g, st, rows, c, x, gamma, beta, mean, invstd, relu, y, ldy, drop, nt);
 }
 
 template <int V, bool E, bool D> struct BnReduceL {
     static void go(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
-                   const float *beta, const float *mean, const float *invstd, int relu, float *partial, long long lddy, BnDrop drop)
+                   const float *beta, const float *mean, const float *invstd, int relu, float *partial, long long lddy, BnDrop drop, int nt)
     {
         const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, E, D>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy,
+        if constexpr (V == 4 && !D) {
+            if (nt) { hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, E, false, true>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy,
+                           gamma, beta, mean, invstd, relu, partial, lddy, drop); return; }
+        }
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, E, D, false>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy,
                            gamma, beta, mean, invstd, relu, partial, lddy, drop);
     }
 };
 static void launch_bn_bwd_reduce(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
                                  const float *beta, const float *mean, const float *invstd, int relu, float *partial, long long lddy,
-                                 BnDrop drop = kNoDrop)
+                                 int nt, BnDrop drop = kNoDrop)
 {
-    bn_dispatch<BnReduceL>(g, (relu & kBnEluIn) != 0, drop.seed != nullptr, g, st, rows, c, x, dy, gamma, beta, mean, invstd, relu, partial, lddy, drop);
+    bn_dispatch<BnReduceL>(g, (relu & kBnEluIn) != 0, drop.seed != nullptr, g, st, rows, c, x, dy, gamma, beta, mean, invstd, relu, partial, lddy, drop, nt);
 }
 
 template <int V, bool E, bool D> struct BnDxL {
     static void go(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
                    const float *beta, const float *mean, const float *invstd, const float *dgamma, const float *dbeta, int relu, float *dx,
-                   float *colsum_partial, long long lddy, BnDrop drop)
+                   float *colsum_partial, long long lddy, BnDrop drop, int nt)
     {
         const size_t lds = sizeof(float) * static_cast<size_t>(g.threads) * 2 * g.vec;
-        hipLaunchKernelGGL((bn_bwd_dx_kernel<V, E, D>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy,
+        if constexpr (V == 4 && !D) {
+            if (nt) { hipLaunchKernelGGL((bn_bwd_dx_kernel<4, E, false, true>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy,
+                           gamma, beta, mean, invstd, dgamma, dbeta, relu, dx, colsum_partial, lddy, drop); return; }
+        }
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<V, E, D, false>), dim3(g.nblk), dim3(g.threads), lds, st, rows, c, g.cv, g.rpb, g.rows_per_block, x, dy,
                            gamma, beta, mean, invstd, dgamma, dbeta, relu, dx, colsum_partial, lddy, drop);
     }
 };
 static void launch_bn_bwd_dx(const BnGeom &g, hipStream_t st, long long rows, int c, const float *x, const float *dy, const float *gamma,
                              const float *beta, const float *mean, const float *invstd, const float *dgamma, const float *dbeta, int relu,
-                             float *dx, float *colsum_partial, long long lddy, BnDrop drop = kNoDrop)
+                             float *dx, float *colsum_partial, long long lddy, int nt, BnDrop drop = kNoDrop)
 {
     bn_dispatch<BnDxL>(g, (relu & kBnEluIn) != 0, drop.seed != nullptr, g, st, rows, c, x, dy, gamma, beta, mean, invstd, dgamma, dbeta, relu, dx,
-                       colsum_partial, lddy, drop);
+                       colsum_partial, lddy, drop, nt);
 }
+
+// streaming loads for the passes whose tensors cannot stay in the Infinity Cache until they are read again (see ldv)
+constexpr long long kBnNtBytes = 200ll << 20;
+static int bn_nt_fwd(long long rows, int c) { return static_cast<long long>(sizeof(float)) * rows * c > kBnNtBytes ? 1 : 0; }
+static int bn_nt_bwd(long long rows, int c) { return 2ll * static_cast<long long>(sizeof(float)) * rows * c > kBnNtBytes ? 1 : 0; }
 
 static bool aligned16(const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 
@@ -990,10 +1019,10 @@ HF_API int hf_bn_relu_fwd_train_ld(long long rows, int c, const float *x, const 
         return launch_status();
     }
     float *partial = static_cast<float *>(workspace);
-    launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0);
+    launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0, bn_nt_fwd(rows, c));
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), 0ull);
-    launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, ldy);
+    launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, ldy, bn_nt_fwd(rows, c));
     return launch_status();
 }
 
@@ -1016,7 +1045,7 @@ HF_API int hf_bn_stats(long long rows, int c, const float *x, float eps, float m
     if (g.vec == 4 && !aligned16(x)) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
-    launch_bn_stats(g, st, rows, c, x, partial, false);
+    launch_bn_stats(g, st, rows, c, x, partial, false, bn_nt_fwd(rows, c));
     launch_bn_stats_finalize(rows, c, g.nblk, partial, eps, momentum, running_mean, running_var, save_mean, save_invstd, st);
     return launch_status();
 }
@@ -1028,7 +1057,7 @@ HF_API int hf_bn_relu_fwd_eval(long long rows, int c, const float *x, const floa
     BnGeom g = bn_geom(rows, c);
     if (g.vec == 4 && !(aligned16(x) && aligned16(y))) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
-    launch_bn_apply(g, st, rows, c, x, gamma, beta, mean, invstd, relu, y, static_cast<long long>(c));
+    launch_bn_apply(g, st, rows, c, x, gamma, beta, mean, invstd, relu, y, static_cast<long long>(c), bn_nt_fwd(rows, c));
     return launch_status();
 }
 
@@ -1052,10 +1081,10 @@ HF_API int hf_bn_relu_bwd_ld(long long rows, int c, const float *x, const float 
         return launch_status();
     }
     float *partial = static_cast<float *>(workspace);
-    launch_bn_bwd_reduce(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy);
+    launch_bn_bwd_reduce(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, lddy, bn_nt_bwd(rows, c));
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
     float *cpart = dx_colsum ? partial : nullptr;  // the reduce partials were consumed by the finalize kernel above
-    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy);
+    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, cpart, lddy, bn_nt_bwd(rows, c));
     if (dx_colsum)
         hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, cpart, dx_colsum);
     return launch_status();
@@ -1093,10 +1122,10 @@ HF_API int hf_bn_dropout_fwd_train(long long rows, int c, const float *x, const 
     if (!bn_offsets_fit(g, c)) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
-    launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0);
+    launch_bn_stats(g, st, rows, c, x, partial, (relu & kBnEluIn) != 0, bn_nt_fwd(rows, c));
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, drop_state, seed_out, salt);
-    launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, static_cast<long long>(c), d);
+    launch_bn_apply(g, st, rows, c, x, gamma, beta, save_mean, save_invstd, relu, y, static_cast<long long>(c), bn_nt_fwd(rows, c), d);
     return launch_status();
 }
 
@@ -1113,9 +1142,9 @@ HF_API int hf_bn_dropout_bwd(long long rows, int c, const float *x, const float 
     if (!bn_offsets_fit(g, c)) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
     float *partial = static_cast<float *>(workspace);
-    launch_bn_bwd_reduce(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, static_cast<long long>(c), d);
+    launch_bn_bwd_reduce(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, relu, partial, static_cast<long long>(c), bn_nt_bwd(rows, c), d);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, c, g.nblk, partial, dgamma, dbeta);
-    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, nullptr, static_cast<long long>(c), d);
+    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, nullptr, static_cast<long long>(c), bn_nt_bwd(rows, c), d);
     return launch_status();
 }
 
@@ -1142,7 +1171,7 @@ HF_API int hf_bn_relu_bwd_dx(long long rows, int c, const float *x, const float 
     BnGeom g = bn_geom(rows, c);
     if (g.vec == 4 && !(aligned16(x) && aligned16(dy) && aligned16(dx))) return HF_EINVAL;
     hipStream_t st = as_stream(stream);
-    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, nullptr, static_cast<long long>(c));
+    launch_bn_bwd_dx(g, st, rows, c, x, dy, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, dx, nullptr, static_cast<long long>(c), bn_nt_bwd(rows, c));
     return launch_status();
 }
 
@@ -1161,7 +1190,7 @@ HF_API int hf_bn_relu_maxpool_fwd(long long groups, int k, int c, const float *z
         BnGeom g = bn_geom(rows, c);
         if (g.vec == 4 && !aligned16(z)) return HF_EINVAL;
         float *partial = static_cast<float *>(workspace);
-        launch_bn_stats(g, st, rows, c, z, partial, false);
+        launch_bn_stats(g, st, rows, c, z, partial, false, bn_nt_fwd(rows, c));
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(bn_finalize_grid(c, g.nblk)), dim3(64 * kBnFinalizeChannels), 0, st, rows, c, g.nblk, partial, eps, momentum,
                            running_mean, running_var, mean, invstd, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), 0ull);
     }
